@@ -1,0 +1,3 @@
+"""eigensolver_amd -- MI355X-native dispersion-relation hot path."""
+from ._lib import Context, EsError, load  # noqa: F401
+from .slab_analytic import SlabSteadyFlow  # noqa: F401

@@ -1,0 +1,100 @@
+"""ctypes binding of libeigensolver_amd.so (the C ABI declared in include/eigensolver_amd.h).
+
+The library is GPU-only.  Loading fails loudly when the shared object is missing -- there is no Python or
+CPU fallback for any entry point.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeigensolver_amd.so")
+
+
+class SlabAnalyticParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("vA_i", "c_i", "vA_e", "c_e", "mach_i", "mach_e", "R1", "cT_i", "cT_e")]
+
+
+class EsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _sig(lib):
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    lib.es_abi_version.restype = i
+    lib.es_status_string.restype = C.c_char_p
+    lib.es_status_string.argtypes = [i]
+    lib.es_context_create.argtypes = [i, vp, C.POINTER(vp)]
+    lib.es_context_destroy.argtypes = [vp]
+    lib.es_last_error.restype = C.c_char_p
+    lib.es_last_error.argtypes = [vp]
+    lib.es_context_synchronize.argtypes = [vp]
+    P = C.POINTER(SlabAnalyticParams)
+    lib.es_slab_analytic_eval.argtypes = [vp, P, i, vp, i, vp, i, vp]
+    lib.es_slab_analytic_scan.argtypes = [vp, P, i, vp, i, vp, i, d, vp, vp, i, C.POINTER(i)]
+    lib.es_slab_analytic_filter.argtypes = [vp, P, i, vp, vp, i, d, vp]
+    for name in dir(lib):
+        pass
+    return lib
+
+
+def load():
+    """Load the shared library (once).  Raises EsError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EsError(f"{LIB_PATH} not found: build it with `python -m eigensolver_amd.build` "
+                          "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        _lib = _sig(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(ctx, status, allow_capacity=False):
+    if status == 0 or (allow_capacity and status == 3):
+        return status
+    lib = load()
+    msg = lib.es_status_string(status).decode()
+    detail = lib.es_last_error(ctx).decode() if ctx else ""
+    raise EsError(f"libeigensolver_amd: {msg}" + (f" ({detail})" if detail else ""))
+
+
+class Context:
+    """Owns an es_context bound to a HIP device and (optionally) a torch stream."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise EsError("no HIP device visible: eigensolver_amd has no CPU path")
+        self.lib = load()
+        self.device = int(device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.torch_stream = stream
+        h = C.c_void_p()
+        st = self.lib.es_context_create(self.device, C.c_void_p(stream.cuda_stream), C.byref(h))
+        if st != 0:
+            raise EsError("es_context_create: " + self.lib.es_status_string(st).decode())
+        self.handle = h
+
+    def synchronize(self):
+        check(self.handle, self.lib.es_context_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.es_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor as c_void_p."""
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())

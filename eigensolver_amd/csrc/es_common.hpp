@@ -1,0 +1,59 @@
+// Internal declarations shared by the translation units of libeigensolver_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/eigensolver_amd.h"
+
+struct es_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // scratch for bracket compaction (grown on demand, never shrunk)
+  uint64_t* d_masks = nullptr;     size_t masks_cap = 0;      // one ballot mask per 64 cells
+  int* d_block_counts = nullptr;   size_t blocks_cap = 0;     // per-256-cell block counts / exclusive offsets
+  int* d_total = nullptr;                                     // device-side total count
+  int* h_total = nullptr;                                     // pinned host mirror
+};
+
+#define ES_HIP_CHECK(ctx, expr)                                                                 \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                    \
+      return ES_ERR_HIP;                                                                        \
+    }                                                                                           \
+  } while (0)
+
+#define ES_REQUIRE(ctx, cond, msg)                                                              \
+  do {                                                                                          \
+    if (!(cond)) {                                                                              \
+      if (ctx) (ctx)->last_error = std::string("invalid argument: ") + (msg);                   \
+      return ES_ERR_INVALID_ARG;                                                                \
+    }                                                                                           \
+  } while (0)
+
+// Grow the compaction scratch so that `cells` cells fit.
+int es_ensure_scan_scratch(es_context* ctx, size_t cells);
+
+// Ordered compaction of flagged cells (flags live as 64-bit wave ballots in ctx->d_masks):
+//   step 1 (done by the caller's flag kernel): masks[c/64], block_counts[c/256]
+//   step 2: exclusive scan of block_counts -> offsets, total
+// Returns the total through ctx->h_total after a stream sync.
+int es_scan_block_counts(es_context* ctx, int nblocks, int* h_total_out);
+
+// Position of a flagged cell inside the ordered output, from the masks and the scanned block offsets.
+__device__ __forceinline__ int es_cell_rank(const uint64_t* __restrict__ masks, const int* __restrict__ block_off,
+                                            long cell) {
+  const long blk = cell >> 8;
+  const int wave_in_blk = (int)((cell >> 6) & 3);
+  const int lane = (int)(cell & 63);
+  int pos = block_off[blk];
+  const uint64_t* m = masks + (blk << 2);
+  for (int w = 0; w < wave_in_blk; ++w) pos += __popcll(m[w]);
+  const uint64_t lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  pos += __popcll(m[wave_in_blk] & lower);
+  return pos;
+}

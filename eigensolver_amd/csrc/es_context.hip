@@ -1,0 +1,115 @@
+// Context, error strings and the ordered-compaction scan shared by the scan / bracket kernels.
+#include "es_common.hpp"
+
+extern "C" int es_abi_version(void) { return ES_ABI_VERSION; }
+
+extern "C" const char* es_status_string(int s) {
+  switch (s) {
+    case ES_SUCCESS: return "success";
+    case ES_ERR_INVALID_ARG: return "invalid argument";
+    case ES_ERR_HIP: return "HIP runtime error";
+    case ES_ERR_CAPACITY: return "output capacity too small";
+    case ES_ERR_NO_DEVICE: return "no HIP device";
+    case ES_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int es_context_create(int device, void* stream, es_context** out) {
+  if (!out) return ES_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ES_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return ES_ERR_INVALID_ARG;
+  es_context* ctx = new es_context();
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return ES_ERR_HIP; }
+  if (hipMalloc(&ctx->d_total, sizeof(int)) != hipSuccess) { delete ctx; return ES_ERR_HIP; }
+  if (hipHostMalloc(&ctx->h_total, sizeof(int)) != hipSuccess) { (void)hipFree(ctx->d_total); delete ctx; return ES_ERR_HIP; }
+  *out = ctx;
+  return ES_SUCCESS;
+}
+
+extern "C" int es_context_destroy(es_context* ctx) {
+  if (!ctx) return ES_SUCCESS;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+  if (ctx->d_block_counts) (void)hipFree(ctx->d_block_counts);
+  if (ctx->d_total) (void)hipFree(ctx->d_total);
+  if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+  delete ctx;
+  return ES_SUCCESS;
+}
+
+extern "C" const char* es_last_error(const es_context* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int es_context_synchronize(es_context* ctx) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ES_SUCCESS;
+}
+
+int es_ensure_scan_scratch(es_context* ctx, size_t cells) {
+  const size_t nmask = (cells + 63) / 64 + 4;
+  const size_t nblk = (cells + 255) / 256 + 1;
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (nmask > ctx->masks_cap) {
+    if (ctx->d_masks) ES_HIP_CHECK(ctx, hipFree(ctx->d_masks));
+    ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_masks, nmask * sizeof(uint64_t)));
+    ctx->masks_cap = nmask;
+  }
+  if (nblk > ctx->blocks_cap) {
+    if (ctx->d_block_counts) ES_HIP_CHECK(ctx, hipFree(ctx->d_block_counts));
+    ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_block_counts, nblk * sizeof(int)));
+    ctx->blocks_cap = nblk;
+  }
+  return ES_SUCCESS;
+}
+
+// Single-workgroup exclusive scan over the per-block counts (<= a few 1e5 entries; latency-bound, off the hot path).
+__global__ __launch_bounds__(1024) void es_block_scan_kernel(int* __restrict__ counts, int n, int* __restrict__ total) {
+  __shared__ int wave_sums[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = (i < n) ? counts[i] : 0;
+    int x = v;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sums[wid] = x;
+    __syncthreads();
+    if (wid == 0) {
+      int s = (lane < 16) ? wave_sums[lane] : 0;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const int y = __shfl_up(s, off);
+        if (lane >= off) s += y;
+      }
+      if (lane < 16) wave_sums[lane] = s;        // inclusive over waves
+    }
+    __syncthreads();
+    const int wave_excl = (wid == 0) ? 0 : wave_sums[wid - 1];
+    const int c = carry;
+    if (i < n) counts[i] = c + wave_excl + x - v;   // exclusive offset
+    __syncthreads();
+    if (tid == 1023) carry = c + wave_sums[15];
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+
+int es_scan_block_counts(es_context* ctx, int nblocks, int* h_total_out) {
+  hipLaunchKernelGGL(es_block_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_block_counts, nblocks, ctx->d_total);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  ES_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *h_total_out = *ctx->h_total;
+  return ES_SUCCESS;
+}

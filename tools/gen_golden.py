@@ -1,0 +1,155 @@
+"""Generate the golden fixtures under tests/golden/ by running the reference here (build container only).
+
+    python tools/gen_golden.py [--only NAME] [--jobs N]
+
+Outputs (all small, committed):
+  tests/golden/slab_analytic.npz      SF-U:107-127 values on a (K, W) grid + the SF-U:166-303 scan results
+  tests/golden/trace_<case>.json      per-evaluation trace of a reference worker call: omega, mismatch d,
+                                      exterior end state (amplitude, slope), fsolve ier, where (main / loop),
+                                      the 3-point refinement calls, and the accepted roots the worker `put`s.
+The reference sources are read as text from /root/reference and executed in memory through
+tools/ref_harness.py; nothing of them is copied into the repository.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+# ----------------------------------------------------------------------------------------------------
+def gen_slab_analytic():
+    import ref_harness as H
+    ns = H.load_worker_module("SF-U")       # runs the SF-U:166-303 scans as written
+    # re-create the *normalised* tube speeds used by the analytic part (the module redefines cT later, SF-U:406)
+    path = os.path.join(H.REF, H.FILES["SF-U"])
+    lines = open(path).read().split("\n")
+    ns2 = {"np": np}
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile("\n".join(lines[62:149]), "<SF-U:63-149>", "exec"), ns2)
+    K = np.linspace(0.05, 3.5, 24)
+    W = np.concatenate([np.linspace(0.0005, 2.9995, 200), np.linspace(ns2["cT_i"]() + 1e-5, ns2["c_i"] - 1e-5, 56)])
+    out = {"K": K, "W": W}
+    names = ["disp_rel_sausage", "disp_rel_kink", "disp_rel_sausage_body", "disp_rel_kink_body"]
+    with np.errstate(all="ignore"):
+        for n in names:
+            D = np.empty((len(K), len(W)))
+            for i, x in enumerate(K):
+                for j, v in enumerate(W):
+                    D[i, j] = ns2[n](v, x)
+            out[n] = D
+    out["R1"] = np.array(ns2["R1"])
+    out["cT_i"] = np.array(ns2["cT_i"]())
+    out["cT_e"] = np.array(ns2["cT_e"]())
+    for a in ["x_out_sausage", "W_array_sausage", "x_out_kink", "W_array_kink",
+              "x_out_sausage_body", "W_array_sausage_body", "x_out_kink_body", "W_array_kink_body",
+              "x_out_sausage_body1", "W_array_sausage_body1", "x_out_kink_body1", "W_array_kink_body1",
+              "D_range", "W_range", "W_body_range", "W_body_range2"]:
+        out["scan_" + a] = np.asarray(ns[a], dtype=float)
+    out["step"] = np.array(ns["step"])
+    np.savez_compressed(os.path.join(GOLD, "slab_analytic.npz"), **out)
+    return "slab_analytic.npz"
+
+
+# ----------------------------------------------------------------------------------------------------
+# worker trace cases: name -> (file key, replacements, [(fn, k, freq-spec)], notes)
+def band(lo, hi, n):
+    return ("band", lo, hi, n)
+
+
+CASES = {
+    # cylinder, non-uniform flow file as checked in: uniform (dr = 1e5, U_i0 = 0)
+    "CF_uniform": ("CF", [], [("kink", 1.5, band(2.05, 4.95, 14)), ("sausage", 1.5, band(2.05, 4.95, 14)),
+                               ("kink", 0.3, band(2.05, 4.95, 10)), ("sausage", 3.9, band(2.05, 4.95, 10)),
+                               ("kink", 2.0, band(0.9, 1.99, 12)), ("sausage", 2.0, band(0.9, 1.99, 12))]),
+    # Gaussian axial flow (edit of CF:126 / CF:130 as the author does by hand)
+    "CF_flow": ("CF", [("dr=1e5", "dr=1."), ("U_i0 = 0.*c_i0", "U_i0 = 0.6*c_i0")],
+                [("kink", 1.5, band(2.7, 4.95, 12)), ("sausage", 1.5, band(2.7, 4.95, 12)),
+                 ("kink", 3.0, band(2.7, 4.95, 10)), ("kink", 0.5, band(2.7, 4.95, 8))]),
+    # cylinder, Gaussian density, as checked in (dr = 0.95) and uniform limit
+    "CDC_w095": ("CD-C", [], [("kink", 2.0, band(2.05, 4.95, 12)), ("sausage", 2.0, band(2.05, 4.95, 12)),
+                               ("kink", 0.7, band(2.05, 4.95, 8)), ("sausage", 3.5, band(2.05, 4.95, 8))]),
+    "CDC_uniform": ("CD-C", [("dr=0.95", "dr=1e5")], [("kink", 2.0, band(2.05, 4.95, 10)),
+                                                       ("sausage", 2.0, band(2.05, 4.95, 10))]),
+    "CDP": ("CD-P", [], [("kink", 2.0, band(0.52, 1.48, 10)), ("sausage", 2.0, band(0.52, 1.48, 10)),
+                         ("kink", 0.8, band(0.52, 1.48, 8))]),
+    # rotational flow files as checked in
+    "CRKF": ("CR-KF", [], [("kink", 0.3, band(1.255, 1.4, 10)), ("kink", 1.0, band(1.2, 1.45, 10))]),
+    "CRSF": ("CR-SF", [], [("sausage", 1.5, band(1.05, 1.4, 10)), ("sausage", 3.0, band(1.05, 1.4, 8))]),
+    "CRKS": ("CR-KS", [], [("kink", 1.0, band(0.7, 0.99, 10))]),
+    # slabs
+    "SFU": ("SF-U", [], [("sausage", 1.0, ("lin", 0.3, 0.6, 12)), ("kink", 1.0, ("lin", 0.3, 0.6, 12)),
+                         ("sausage", 2.5, ("lin", 0.8, 1.6, 10)), ("kink", 0.4, ("lin", 0.1, 0.3, 10))]),
+    "SFG_uniform": ("SF-G", [], [("sausage", 1.0, band(1.05, 2.45, 10)), ("kink", 1.0, band(1.05, 2.45, 10))]),
+    "SFG_flow": ("SF-G", [("dx=1e5", "dx=1.5"), ("U_i0 = 0.9*vA_i", "U_i0 = 0.35*vA_i")],
+                 [("sausage", 1.0, band(1.4, 2.45, 10)), ("kink", 1.0, band(1.4, 2.45, 10)),
+                  ("kink", 2.5, band(1.4, 2.45, 8))]),
+    "SDP_uniform": ("SD-P", [("1e5)  # inside slab x values", "2001)  # inside slab x values")],
+                    [("sausage", 1.0, band(0.9, 0.99, 8)), ("kink", 1.0, band(0.9, 0.99, 8))]),
+    "SDP_w15": ("SD-P", [("1e5)  # inside slab x values", "2001)  # inside slab x values"), ("dx=1e5", "dx=1.5")],
+                [("sausage", 1.0, band(0.9, 1.25, 8)), ("kink", 1.0, band(0.9, 1.25, 8)),
+                 ("kink", 2.5, band(0.9, 1.25, 8))]),
+}
+
+
+def make_freq(spec, k):
+    if spec[0] == "band":
+        return np.linspace(spec[1] * k, spec[2] * k, spec[3])
+    return np.linspace(spec[1], spec[2], spec[3])
+
+
+def gen_case(name):
+    import ref_harness as H
+    key, repl, calls = CASES[name]
+    t0 = time.time()
+    ns = H.load_worker_module(key, repl)
+    init = H.snapshot_initial(ns)
+    out = {"case": name, "file": H.FILES[key], "replacements": repl, "calls": []}
+    for k_ in ("xi_tol", "p_tol", "P_tol"):
+        if k_ in ns:
+            out[k_] = float(ns[k_])
+    for fn, k, spec in calls:
+        freq = make_freq(spec, k)
+        rw, rk, tr = H.run_worker(ns, init, fn, float(k), freq)
+        evs = H.evaluations(tr)
+        rec = {"fn": fn, "k": float(k), "freq": [float(x) for x in freq], "roots_w": rw, "roots_k": rk,
+               "linspace3": [[e[1], e[2]] for e in tr if e[0] == "linspace3"],
+               "evals": [{"omega": e["omega"], "d": e["d"], "ext_end": e["ext_end"], "ier": e["ier"],
+                          "where": e["where"], "int_y0": e.get("int_y0"), "int_end": e.get("int_end"),
+                          "slope": e.get("slope")} for e in evs]}
+        out["calls"].append(rec)
+    out["seconds"] = round(time.time() - t0, 1)
+    with open(os.path.join(GOLD, f"trace_{name}.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return f"trace_{name}.json ({out['seconds']} s, {sum(len(c['evals']) for c in out['calls'])} evals)"
+
+
+def _run(name):
+    try:
+        if name == "slab_analytic":
+            return gen_slab_analytic()
+        return gen_case(name)
+    except Exception as e:  # noqa
+        import traceback
+        return f"{name}: FAILED {type(e).__name__}: {e}\n{traceback.format_exc()}"
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--jobs", type=int, default=6)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    names = ["slab_analytic"] + list(CASES)
+    if a.only:
+        names = [n for n in names if n in a.only.split(",")]
+    import multiprocessing as mp
+    with mp.Pool(a.jobs) as pool:
+        for msg in pool.imap_unordered(_run, names):
+            print(msg, flush=True)
