@@ -1,3 +1,5 @@
 """eigensolver_amd -- MI355X-native dispersion-relation hot path."""
 from ._lib import Context, EsError, load  # noqa: F401
 from .slab_analytic import SlabSteadyFlow  # noqa: F401
+from . import equilibrium  # noqa: F401
+from .shooting import ShootProblem  # noqa: F401

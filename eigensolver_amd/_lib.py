@@ -98,3 +98,45 @@ def ptr(t):
     """Device pointer of a contiguous torch tensor as c_void_p."""
     assert t.is_contiguous()
     return C.c_void_p(t.data_ptr())
+
+
+# ---- shooting path structs (include/eigensolver_amd.h section 2) ---------------------------------------------
+class ShootDesc(C.Structure):
+    _fields_ = [("geometry", C.c_int32), ("n_nodes", C.c_int32),
+                ("x_boundary", C.c_double), ("x_end", C.c_double),
+                ("rho_e", C.c_double), ("vA_e", C.c_double), ("c_e", C.c_double), ("cT_e", C.c_double),
+                ("U_e", C.c_double), ("L_factor", C.c_double), ("ic_value", C.c_double), ("ic_slope", C.c_double),
+                ("m", C.c_int32), ("m_ext", C.c_int32), ("axis_bc", C.c_int32), ("c1_power", C.c_int32),
+                ("bc_const", C.c_double),
+                ("slab_mode", C.c_int32), ("reserved", C.c_int32),
+                ("c_i", C.c_double), ("vA_i", C.c_double), ("rho_i", C.c_double)]
+
+
+_PROFILE_FIELDS = ("r", "rho", "c2", "vA2", "Bz", "Bphi", "vz", "vphi", "rdC3", "U", "dU", "ddU")
+
+
+class Profiles(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PROFILE_FIELDS]
+
+
+class RootTable(C.Structure):
+    _fields_ = [("d_k", C.c_void_p), ("d_w", C.c_void_p), ("d_w_lo", C.c_void_p), ("d_w_hi", C.c_void_p),
+                ("d_resid", C.c_void_p), ("d_row", C.c_void_p), ("d_flag", C.c_void_p), ("capacity", C.c_int32)]
+
+
+def _sig_shoot(lib):
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    lib.es_problem_create.argtypes = [vp, C.POINTER(ShootDesc), C.POINTER(Profiles), C.POINTER(vp)]
+    lib.es_problem_destroy.argtypes = [vp, vp]
+    lib.es_shoot_eval_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, vp]
+    lib.es_shoot_eval_points.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
+    lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
+
+
+_orig_sig = _sig
+
+
+def _sig(lib):  # noqa: F811
+    _orig_sig(lib)
+    _sig_shoot(lib)
+    return lib

@@ -1,0 +1,544 @@
+// K3/K4/K5: shooting evaluation of D(k, omega) on a (k, omega) grid, bracket detection, bisection refinement and
+// ordered root compaction.  See es_shoot_device.hpp for the arithmetic and include/eigensolver_amd.h for the
+// reference lines each entry point replaces.
+//
+// Kernel layout (DESIGN.md section "kernels"):
+//  * shoot_grid_kernel<FAM, PTS>: one workgroup per k-row, omega along the lanes (PTS points per lane, strided by
+//    the workgroup size so the 8-byte D stores of a wave are one contiguous 512 B segment).  k is workgroup
+//    uniform, so everything that depends on (node, k, m) but not on omega is computed ONCE per row into an LDS
+//    table, chunk by chunk (CH RK4 steps per chunk); every lane then reads the same LDS address (broadcast).
+//  * shoot_points_kernel<FAM>: one (k, omega) pair per lane with unrelated k: the k-independent base table is
+//    read with wave-uniform addresses (scalar loads), node entries are formed per lane.  Used for refinement.
+//  * bracket_flag_kernel: sign change against the omega-neighbour through __shfl_down (lane 63 reads the halo
+//    element), ballot masks + per-block counts; bracket_emit_kernel writes the ordered bracket list.
+//  * refine_kernel: one bracket per lane, fixed number of bisection steps (uniform trip count -> no divergence),
+//    final classification with the reference's acceptance measure.
+#include "es_common.hpp"
+#include "es_shoot_device.hpp"
+#include <vector>
+#include <cstdlib>
+
+struct es_problem {
+  ShootDev dev;
+  double* d_base = nullptr;
+  es_shoot_desc desc;
+};
+
+namespace {
+
+constexpr int CH = 128;   // RK4 steps per LDS chunk: (2*CH+1) * NE * 8 B of LDS (12.3 KiB for NE = 6)
+
+template <int FAM>
+__device__ __forceinline__ void load_base(const ShootDev& P, int pt, double* b) {
+#pragma unroll
+  for (int f = 0; f < FamTraits<FAM>::NB; ++f) b[f] = P.base[(size_t)f * P.npts + pt];
+}
+
+__device__ __forceinline__ double pick_w(const double* __restrict__ wv, int w_mode, double k, int row, int nw, int iw) {
+  if (w_mode == ES_W_PHASE_SPEED) return k * wv[iw];
+  if (w_mode == ES_W_PER_ROW) return wv[(size_t)row * nw + iw];
+  return wv[iw];
+}
+
+// Deliberately NOT inlined: the Bessel series / continued fraction need ~100 VGPRs of their own; as a real call
+// they stay out of the register allocation of the RK4 loop (the call sits after the loop, once per point).
+__device__ __noinline__ Exterior exterior_any(const ShootDev& P, double k, double w) {
+  return (P.family == FAM_CYL0 || P.family == FAM_CYLT) ? exterior_cylinder(P, k, w) : exterior_slab(P, k, w);
+}
+
+__device__ __forceinline__ void finish_point(const Mismatch& M, const Exterior& X, bool crossed, double& D,
+                                             double& rel, uint8_t& st) {
+  st = (uint8_t)X.status;
+  D = M.d;
+  const double sc = fmax(fabs(M.outer), fabs(M.inner));
+  rel = fabs(M.d) * 100.0 / sc;                       // CF:817
+  if (X.status != ES_PT_OK) { D = NAN; rel = NAN; return; }
+  if (!isfinite(D)) { st = ES_PT_NONFINITE; return; }
+  if (crossed) st = ES_PT_CONTINUUM;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int FAM, int PTS, int MAXT>
+__global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
+                                                          const double* __restrict__ wv, int nw, int w_mode,
+                                                          double* __restrict__ Dout, double* __restrict__ relout,
+                                                          uint8_t* __restrict__ stout) {
+  constexpr int NE = FamTraits<FAM>::NE;
+  constexpr bool DIAG = FamTraits<FAM>::DIAG;
+  constexpr int LSTRIDE = 2 * CH + 1;
+  __shared__ double lds[NE * LSTRIDE];
+  const int T = blockDim.x;
+  const int nsteps = P.n_nodes - 1;
+  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0;
+
+  for (int row = blockIdx.x; row < nk; row += gridDim.x) {
+    const double k = kv[row];
+    const KScal s = make_kscal(P, k);
+    for (int w0 = 0; w0 < nw; w0 += T * PTS) {
+      double w[PTS], u1[PTS], v1[PTS], u2[PTS], v2[PTS];
+      Coef A0[PTS];
+      SignTrack trk[PTS];
+      bool inr[PTS];
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) {
+        const int iw = w0 + p * T + (int)threadIdx.x;
+        inr[p] = iw < nw;
+        w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
+        u1[p] = 1.0; v1[p] = 0.0; u2[p] = 0.0; v2[p] = 1.0;
+      }
+      for (int c0 = 0; c0 < nsteps; c0 += CH) {
+        const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
+        __syncthreads();                               // previous chunk fully consumed
+        for (int i = threadIdx.x; i < 2 * nst + 1; i += T) {
+          double b[FamTraits<FAM>::NB], e[NE];
+          load_base<FAM>(P, 2 * c0 + i, b);
+          make_entry<FAM>(b, s, e);
+#pragma unroll
+          for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = e[f];
+        }
+        __syncthreads();
+        if (c0 == 0) {
+          double e0[NE];
+#pragma unroll
+          for (int f = 0; f < NE; ++f) e0[f] = lds[f * LSTRIDE];
+#pragma unroll
+          for (int p = 0; p < PTS; ++p) coefficients<FAM>(e0, P, s, w[p], A0[p], trk[p]);
+        }
+        for (int j = 0; j < nst; ++j) {
+          double em[NE], e1[NE];
+#pragma unroll
+          for (int f = 0; f < NE; ++f) {
+            em[f] = lds[f * LSTRIDE + 2 * j + 1];
+            e1[f] = lds[f * LSTRIDE + 2 * j + 2];
+          }
+#pragma unroll
+          for (int p = 0; p < PTS; ++p) {
+            Coef Am, A1;
+            coefficients<FAM>(em, P, s, w[p], Am, trk[p]);
+            coefficients<FAM>(e1, P, s, w[p], A1, trk[p]);
+            rk4_step<DIAG>(u1[p], v1[p], u2[p], v2[p], A0[p], Am, A1, h, h2, h6);
+            A0[p] = A1;
+          }
+        }
+      }
+      // boundary: exterior closed form + axis / symmetry condition + mismatch
+      double bf[FamTraits<FAM>::NB], ef[NE];
+      load_base<FAM>(P, 0, bf);
+      make_entry<FAM>(bf, s, ef);
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) {
+        if (!inr[p]) continue;
+        const int iw = w0 + p * T + (int)threadIdx.x;
+        const Exterior X = exterior_any(P, k, w[p]);
+        const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X, u1[p], v1[p], u2[p], v2[p], ef, A0[p]);
+        double D, rel; uint8_t st;
+        finish_point(M, X, trk[p].crossed(), D, rel, st);
+        const size_t o = (size_t)row * nw + iw;
+        Dout[o] = D;
+        stout[o] = st;
+        if (relout) relout[o] = rel;
+      }
+    }
+  }
+}
+
+// One (k, omega) pair per lane.  Base-table indices are wave-uniform -> scalar loads.
+template <int FAM>
+__device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double& D, double& rel,
+                                            uint8_t& st) {
+  constexpr int NE = FamTraits<FAM>::NE;
+  constexpr int NB = FamTraits<FAM>::NB;
+  constexpr bool DIAG = FamTraits<FAM>::DIAG;
+  const KScal s = make_kscal(P, k);
+  const int nsteps = P.n_nodes - 1;
+  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0;
+  double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0;
+  SignTrack trk;
+  double b[NB], ef[NE], e[NE];
+  load_base<FAM>(P, 0, b);
+  make_entry<FAM>(b, s, ef);
+  Coef A0;
+  coefficients<FAM>(ef, P, s, w, A0, trk);
+  for (int j = 0; j < nsteps; ++j) {
+    Coef Am, A1;
+    load_base<FAM>(P, 2 * j + 1, b);
+    make_entry<FAM>(b, s, e);
+    coefficients<FAM>(e, P, s, w, Am, trk);
+    load_base<FAM>(P, 2 * j + 2, b);
+    make_entry<FAM>(b, s, e);
+    coefficients<FAM>(e, P, s, w, A1, trk);
+    rk4_step<DIAG>(u1, v1, u2, v2, A0, Am, A1, h, h2, h6);
+    A0 = A1;
+  }
+  const Exterior X = exterior_any(P, k, w);
+  const Mismatch M = boundary_algebra<FAM>(P, s, w, X, u1, v1, u2, v2, ef, A0);
+  finish_point(M, X, trk.crossed(), D, rel, st);
+}
+
+template <int FAM>
+__global__ __launch_bounds__(256) void shoot_points_kernel(ShootDev P, const double* __restrict__ kv,
+                                                           const double* __restrict__ wv, int n,
+                                                           double* __restrict__ Dout, double* __restrict__ relout,
+                                                           uint8_t* __restrict__ stout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < n;
+  const double k = in ? kv[i] : 1.0;
+  const double w = in ? wv[i] : 1.0;
+  double D, rel; uint8_t st;
+  shoot_point<FAM>(P, k, w, D, rel, st);
+  if (in) {
+    Dout[i] = D;
+    stout[i] = st;
+    if (relout) relout[i] = rel;
+  }
+}
+
+// ---- brackets ------------------------------------------------------------------------------------------------
+// cell c = row*nw + j ; bracket if j < nw-1, both ends ES_PT_OK and D[c]*D[c+1] < 0 (sign product as in CF:806).
+__global__ __launch_bounds__(256) void bracket_flag_kernel(const double* __restrict__ D,
+                                                           const uint8_t* __restrict__ st, int nw, long cells,
+                                                           uint64_t* __restrict__ masks,
+                                                           int* __restrict__ block_counts) {
+  __shared__ int wave_cnt[4];
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  double d0 = 0.0; int ok0 = 0;
+  if (c < cells) { d0 = D[c]; ok0 = (st[c] == ES_PT_OK); }
+  // neighbour in omega: lane+1 of the same wave, or the halo element for lane 63
+  double d1 = __shfl_down(d0, 1);
+  int ok1 = __shfl_down(ok0, 1);
+  if (lane == 63) {
+    if (c + 1 < cells) { d1 = D[c + 1]; ok1 = (st[c + 1] == ES_PT_OK); } else { d1 = 0.0; ok1 = 0; }
+  }
+  bool flag = false;
+  if (c < cells) {
+    const long row = c / nw;
+    const int j = (int)(c - row * nw);
+    flag = (j < nw - 1) && ok0 && ok1 && (d0 * d1 < 0.0);
+  }
+  const uint64_t m = __ballot(flag);
+  if (lane == 0) {
+    masks[c >> 6] = m;
+    wave_cnt[threadIdx.x >> 6] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restrict__ kv,
+                                                           const double* __restrict__ wv, int nw, int w_mode,
+                                                           long cells, const double* __restrict__ D,
+                                                           const uint64_t* __restrict__ masks,
+                                                           const int* __restrict__ block_off, es_root_table tab,
+                                                           double* __restrict__ d_lo_sign) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cells) return;
+  const uint64_t m = masks[c >> 6];
+  if (!((m >> (c & 63)) & 1ull)) return;
+  const int pos = es_cell_rank(masks, block_off, c);
+  if (pos >= tab.capacity) return;
+  const long row = c / nw;
+  const int j = (int)(c - row * nw);
+  const double k = kv[row];
+  tab.d_k[pos] = k;
+  tab.d_row[pos] = (int32_t)row;
+  tab.d_w_lo[pos] = pick_w(wv, w_mode, k, (int)row, nw, j);
+  tab.d_w_hi[pos] = pick_w(wv, w_mode, k, (int)row, nw, j + 1);
+  d_lo_sign[pos] = D[c];
+}
+
+// One bracket per lane; n_bisect bisection steps with the midpoint of np.linspace(lo, hi, 3), then classification.
+template <int FAM>
+__global__ __launch_bounds__(256) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
+                                                     int n, int n_bisect, double tol_percent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < n;
+  const double k = in ? tab.d_k[i] : 1.0;
+  double lo = in ? tab.d_w_lo[i] : 1.0;
+  double hi = in ? tab.d_w_hi[i] : 2.0;
+  double flo = in ? d_lo[i] : 1.0;
+  double D, rel; uint8_t st;
+  for (int it = 0; it < n_bisect; ++it) {
+    const double mid = lo + (hi - lo) * 0.5;
+    shoot_point<FAM>(P, k, mid, D, rel, st);
+    // a non-finite / skipped midpoint keeps the lower end (NaN products compare false, as in the reference)
+    if (D * flo < 0.0) { hi = mid; } else { lo = mid; flo = (D == D) ? D : flo; }
+  }
+  const double root = lo + (hi - lo) * 0.5;
+  shoot_point<FAM>(P, k, root, D, rel, st);
+  if (in) {
+    tab.d_w[i] = root;
+    tab.d_w_lo[i] = lo;
+    tab.d_w_hi[i] = hi;
+    tab.d_resid[i] = rel;
+    tab.d_flag[i] = (st == ES_PT_OK && rel < tol_percent) ? 1 : 0;
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+int check_problem(es_context* ctx, const es_problem* prob) {
+  ES_REQUIRE(ctx, prob != nullptr, "null problem");
+  return ES_SUCCESS;
+}
+
+// Launch geometry of the grid kernel: workgroup = one k-row, threads cover omega, PTS points per lane.
+//   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)      -- default for wide rows
+//   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD)
+//   variant 2: PTS = 1, up to 1024 threads
+// ES_GRID_VARIANT in the environment overrides the default (tuning aid).
+template <int FAM>
+int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
+                int w_mode, double* d_D, double* d_rel, uint8_t* d_status) {
+  const int grid = nk < 65535 ? nk : 65535;
+  int variant = (nw >= 1024) ? 0 : 2;
+  if (const char* ev = getenv("ES_GRID_VARIANT")) variant = atoi(ev);
+  auto roundT = [](int pts_needed, int maxT) {
+    int T = (pts_needed + 63) / 64 * 64;
+    if (T < 64) T = 64;
+    if (T > maxT) T = maxT;
+    return T;
+  };
+  if (variant == 1) {
+    const int T = roundT((nw + 3) / 4, 512);
+    hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 512>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);
+  } else if (variant == 0) {
+    const int T = roundT((nw + 1) / 2, 1024);
+    hipLaunchKernelGGL((shoot_grid_kernel<FAM, 2, 1024>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);
+  } else {
+    const int T = roundT(nw, 1024);
+    hipLaunchKernelGGL((shoot_grid_kernel<FAM, 1, 1024>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);
+  }
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
+}
+
+template <int FAM>
+int launch_points(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w, int n,
+                  double* d_D, double* d_rel, uint8_t* d_status) {
+  hipLaunchKernelGGL((shoot_points_kernel<FAM>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, prob->dev, d_k,
+                     d_w, n, d_D, d_rel, d_status);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
+}
+
+template <int FAM>
+int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const double* d_lo, int n,
+                  int n_bisect, double tol) {
+  hipLaunchKernelGGL((refine_kernel<FAM>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, n,
+                     n_bisect, tol);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
+}
+
+#define ES_DISPATCH_FAMILY(fam, CALL)                      \
+  switch (fam) {                                           \
+    case FAM_CYL0: return CALL(FAM_CYL0);                  \
+    case FAM_CYLT: return CALL(FAM_CYLT);                  \
+    case FAM_SLABD: return CALL(FAM_SLABD);                \
+    case FAM_SLABF: return CALL(FAM_SLABF);                \
+    default: return ES_ERR_UNSUPPORTED;                    \
+  }
+
+}  // namespace
+
+// ---- problem creation: pack the k-independent base fields (host, fp64) and upload them -----------------------
+extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const es_profiles* pr, es_problem** out) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, d && pr && out, "null pointer");
+  *out = nullptr;
+  ES_REQUIRE(ctx, d->n_nodes >= 2 && d->n_nodes <= (1 << 24), "n_nodes out of range");
+  ES_REQUIRE(ctx, d->geometry >= 0 && d->geometry <= 3, "geometry");
+  ES_REQUIRE(ctx, d->x_boundary == -1.0 || d->x_boundary == 1.0, "x_boundary must be -1 or +1");
+  const int N = d->n_nodes, npts = 2 * N - 1;
+  int nb = 0;
+  switch (d->geometry) {
+    case ES_GEOM_CYLINDER: nb = FamTraits<FAM_CYL0>::NB; break;
+    case ES_GEOM_CYLINDER_TWIST: nb = FamTraits<FAM_CYLT>::NB; break;
+    case ES_GEOM_SLAB_DENSITY: nb = FamTraits<FAM_SLABD>::NB; break;
+    default: nb = FamTraits<FAM_SLABF>::NB; break;
+  }
+  std::vector<double> base((size_t)nb * npts);
+  auto B = [&](int f, int i) -> double& { return base[(size_t)f * npts + i]; };
+  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_CYLINDER_TWIST) {
+    ES_REQUIRE(ctx, pr->r && pr->rho && pr->c2 && pr->Bz, "cylinder profiles r, rho, c2, Bz required");
+    ES_REQUIRE(ctx, d->axis_bc >= 0 && d->axis_bc <= 2, "axis_bc");
+    ES_REQUIRE(ctx, d->c1_power == 1 || d->c1_power == 2, "c1_power");
+    ES_REQUIRE(ctx, d->m >= 0 && d->m_ext >= 0 && d->m_ext <= 64, "m");
+    for (int i = 0; i < npts; ++i) {
+      const double r = pr->r[i], rho = pr->rho[i], c2 = pr->c2[i], Bz = pr->Bz[i];
+      const double Bphi = pr->Bphi ? pr->Bphi[i] : 0.0;
+      const double vz = pr->vz ? pr->vz[i] : 0.0;
+      const double vphi = pr->vphi ? pr->vphi[i] : 0.0;
+      const double sr = sqrt(rho);
+      const double bA = Bz / sr;                    // (k B_z)/sqrt(rho) per unit k, CF:581
+      const double vA = (Bz + Bphi) / sr;           // vA_i as written, CF:173-174
+      const double S = c2 + vA * vA;
+      const double q = c2 / S;
+      if (d->geometry == ES_GEOM_CYLINDER) {
+        ES_REQUIRE(ctx, Bphi == 0.0 && vphi == 0.0, "ES_GEOM_CYLINDER needs Bphi = vphi = 0 (use CYLINDER_TWIST)");
+        B(C0_VZ, i) = vz;
+        B(C0_BA, i) = bA;
+        B(C0_Q, i) = q;
+        B(C0_A1, i) = rho / r;
+        B(C0_B1, i) = r / (rho * S);
+        B(C0_E1, i) = 1.0 / (r * rho);
+        B(C0_E2, i) = r / rho;
+      } else {
+        B(CT_R, i) = r;
+        B(CT_INVR, i) = 1.0 / r;
+        B(CT_RHO, i) = rho;
+        B(CT_S, i) = S;
+        B(CT_Q, i) = q;
+        B(CT_BA, i) = bA;
+        B(CT_BZ, i) = Bz;
+        B(CT_BPHR, i) = Bphi / r;
+        B(CT_VPHR, i) = vphi / r;
+        B(CT_VZ, i) = vz;
+        B(CT_RDC3, i) = pr->rdC3 ? pr->rdC3[i] : 0.0;
+      }
+    }
+  } else if (d->geometry == ES_GEOM_SLAB_DENSITY) {
+    ES_REQUIRE(ctx, pr->rho && pr->c2 && pr->vA2, "slab density profiles rho, c2, vA2 required");
+    for (int i = 0; i < npts; ++i) {
+      B(SD_RHO, i) = pr->rho[i];
+      B(SD_C2, i) = pr->c2[i];
+      B(SD_VA2, i) = pr->vA2[i];
+    }
+  } else {
+    ES_REQUIRE(ctx, pr->U, "slab flow profile U required");
+    for (int i = 0; i < npts; ++i) {
+      B(SF_U, i) = pr->U[i];
+      B(SF_DU, i) = pr->dU ? pr->dU[i] : 0.0;
+      B(SF_DDU, i) = pr->ddU ? pr->ddU[i] : 0.0;
+    }
+  }
+  es_problem* p = new es_problem();
+  p->desc = *d;
+  ShootDev& S = p->dev;
+  memset(&S, 0, sizeof(S));
+  S.family = d->geometry;
+  S.n_nodes = N;
+  S.npts = npts;
+  S.xb = d->x_boundary;
+  S.h = (d->x_end - d->x_boundary) / (double)(N - 1);
+  S.rho_e = d->rho_e;
+  S.vAe2 = d->vA_e * d->vA_e;
+  S.ce2 = d->c_e * d->c_e;
+  S.cTe2 = d->cT_e * d->cT_e;
+  S.Se = S.vAe2 + S.ce2;
+  S.U_e = d->U_e;
+  S.R_factor = d->L_factor * 2.0 * 3.14159265358979323846;
+  S.ic0 = d->ic_value;
+  S.ic1 = d->ic_slope;
+  S.m = d->m; S.m_ext = d->m_ext; S.axis_bc = d->axis_bc; S.c1_power = d->c1_power;
+  S.bc_const = d->bc_const;
+  S.slab_sign = (d->slab_mode == ES_SLAB_MODE_SAUSAGE) ? -1.0 : 1.0;
+  S.c2_i = d->c_i * d->c_i;
+  S.vA2_i = d->vA_i * d->vA_i;
+  S.S_i = S.c2_i + S.vA2_i;
+  S.cT2_i = (S.S_i > 0.0) ? S.c2_i * S.vA2_i / S.S_i : 0.0;
+  S.rho_i = d->rho_i;
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      hipMalloc(&p->d_base, base.size() * sizeof(double)) != hipSuccess) {
+    ctx->last_error = "hipMalloc(base table) failed";
+    delete p;
+    return ES_ERR_HIP;
+  }
+  if (hipMemcpyAsync(p->d_base, base.data(), base.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    ctx->last_error = "upload of base table failed";
+    (void)hipFree(p->d_base);
+    delete p;
+    return ES_ERR_HIP;
+  }
+  S.base = p->d_base;
+  *out = p;
+  return ES_SUCCESS;
+}
+
+extern "C" int es_problem_destroy(es_context* ctx, es_problem* prob) {
+  if (!prob) return ES_SUCCESS;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (prob->d_base) (void)hipFree(prob->d_base);
+  delete prob;
+  return ES_SUCCESS;
+}
+
+extern "C" int es_shoot_eval_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                  const double* d_w, int nw, int w_mode, double* d_D, double* d_rel,
+                                  uint8_t* d_status) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, nk >= 0 && nw >= 0, "negative size");
+  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  if (nk == 0 || nw == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+#define CALL_GRID(F) launch_grid<F>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status)
+  ES_DISPATCH_FAMILY(prob->dev.family, CALL_GRID)
+#undef CALL_GRID
+}
+
+extern "C" int es_shoot_eval_points(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w,
+                                    int n, double* d_D, double* d_rel, uint8_t* d_status) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, n >= 0, "negative size");
+  if (n == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+#define CALL_PTS(F) launch_points<F>(ctx, prob, d_k, d_w, n, d_D, d_rel, d_status)
+  ES_DISPATCH_FAMILY(prob->dev.family, CALL_PTS)
+#undef CALL_PTS
+}
+
+extern "C" int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                   const double* d_w, int nw, int w_mode, const double* d_D,
+                                   const uint8_t* d_status, int n_bisect, double tol_percent, es_root_table* table,
+                                   int* h_count) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, table && h_count, "null pointer");
+  ES_REQUIRE(ctx, nk >= 0 && nw >= 0 && n_bisect >= 0 && table->capacity >= 0, "negative size");
+  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  *h_count = 0;
+  const long cells = (long)nk * nw;
+  if (cells == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  ES_REQUIRE(ctx, table->capacity == 0 || (table->d_k && table->d_w && table->d_w_lo && table->d_w_hi &&
+                                           table->d_resid && table->d_row && table->d_flag),
+             "null root table arrays");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  rc = es_ensure_scan_scratch(ctx, (size_t)cells);
+  if (rc) return rc;
+  const int nblocks = (int)((cells + 255) / 256);
+  hipLaunchKernelGGL(bracket_flag_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_D, d_status, nw, cells,
+                     ctx->d_masks, ctx->d_block_counts);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  int total = 0;
+  rc = es_scan_block_counts(ctx, nblocks, &total);
+  if (rc) return rc;
+  *h_count = total;
+  const int n = total < table->capacity ? total : table->capacity;
+  if (n > 0) {
+    // the d_w column doubles as scratch for D at the lower bracket end until refinement overwrites it
+    hipLaunchKernelGGL(bracket_emit_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w, nw, w_mode, cells,
+                       d_D, ctx->d_masks, ctx->d_block_counts, *table, table->d_w);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+#define CALL_REF(F) launch_refine<F>(ctx, prob, *table, table->d_w, n, n_bisect, tol_percent)
+    int rr;
+    switch (prob->dev.family) {
+      case FAM_CYL0: rr = CALL_REF(FAM_CYL0); break;
+      case FAM_CYLT: rr = CALL_REF(FAM_CYLT); break;
+      case FAM_SLABD: rr = CALL_REF(FAM_SLABD); break;
+      case FAM_SLABF: rr = CALL_REF(FAM_SLABF); break;
+      default: rr = ES_ERR_UNSUPPORTED;
+    }
+#undef CALL_REF
+    if (rr) return rr;
+  }
+  return total > table->capacity ? ES_ERR_CAPACITY : ES_SUCCESS;
+}

@@ -1,0 +1,359 @@
+// Device-side pieces of the shooting evaluation of the boundary determinant D(k, omega):
+//   * per-family coefficient sets of the interior first-order system  y' = A(x; k, omega) y,  y = (u, v)
+//   * the fixed-grid RK4 propagation of the 2x2 transfer matrix from the boundary to the far end of the interior
+//   * the closed-form exterior solution with the reference's far-field initial values
+//   * the boundary algebra (axis / symmetry condition by superposition, mismatch)
+//
+// Families (reference rows a3-a7 of SURVEY.md section 8):
+//   FAM_CYL0   cylinder without twist/rotation (CD-C, CD-P, CF):   u = P, v = Xi = r*xi
+//                  P'  = rho (Om^2 - wA^2)/r * Xi ,   Xi' = -r C2/D * P
+//   FAM_CYLT   cylinder, general Hain-Luest/SGH set with v_phi, B_phi (CR-*):
+//                  P'  = -C1/D P + C3/(r D) Xi ,      Xi' = -r C2/D P + C1/D Xi
+//   FAM_SLABD  slab, non-uniform density (SD-P, SD-C), flux form:  u = Vx, v = F Vx'
+//                  u'  = v/F ,                        v'  = F m0 u = rho (k^2 vA^2 - w^2) u
+//   FAM_SLABF  slab with flow (SF-U uniform, SF-G Gaussian), as written in the reference: u = Vx, v = Vx'
+//                  u'  = v ,                          v'  = -D v - coeff u
+// All arithmetic is written out operation by operation (the translation unit is compiled with
+// -ffp-contract=off; fused multiply-adds appear only as explicit fma() calls) and is mirrored line by line by the
+// CPU port in oracle/c/shoot_port.c, so that the two agree to the last bit wherever no libm call is involved.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "es_bessel.hpp"
+#include "../../include/eigensolver_amd.h"
+
+enum { FAM_CYL0 = 0, FAM_CYLT = 1, FAM_SLABD = 2, FAM_SLABF = 3 };
+
+// Plain-data description of one problem, passed by value to the kernels.
+struct ShootDev {
+  int family;
+  int n_nodes;        // interior nodes N (RK4 steps = N-1); base tables hold 2N-1 points (nodes + midpoints)
+  int npts;
+  double xb;          // first node (boundary): -1 or +1
+  double h;           // signed RK4 step
+  const double* base; // [NB][npts] in HBM
+  // exterior medium
+  double rho_e, vAe2, ce2, cTe2, Se, U_e;
+  double R_factor;    // far field at |x| = R_factor / k   (L * 2 pi)
+  double ic0, ic1;    // far-field initial values of the reference's exterior solve
+  // cylinder
+  int m, m_ext, axis_bc, c1_power;
+  double bc_const;
+  // slab
+  double slab_sign;   // -1 sausage: Vx(+1) = -Vx(-1);  +1 kink
+  double c2_i, vA2_i, S_i, cT2_i, rho_i;   // uniform interior speeds of the flow slab
+};
+
+template <int FAM> struct FamTraits;
+template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 6; static constexpr bool DIAG = false; };
+template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 11, NE = 16; static constexpr bool DIAG = true; };
+template <> struct FamTraits<FAM_SLABD> { static constexpr int NB = 3, NE = 5; static constexpr bool DIAG = false; };
+template <> struct FamTraits<FAM_SLABF> { static constexpr int NB = 3, NE = 3; static constexpr bool DIAG = true; };
+
+// base-field indices
+enum { C0_VZ = 0, C0_BA, C0_Q, C0_A1, C0_B1, C0_E1, C0_E2 };
+enum { CT_R = 0, CT_INVR, CT_RHO, CT_S, CT_Q, CT_BA, CT_BZ, CT_BPHR, CT_VPHR, CT_VZ, CT_RDC3 };
+enum { SD_RHO = 0, SD_C2, SD_VA2 };
+enum { SF_U = 0, SF_DU, SF_DDU };
+
+struct Coef { double a11, a12, a21, a22; };
+
+// per-(k, m) scalars that do not depend on the node
+struct KScal {
+  double k, k2, m, m2;
+  double kc2, kvA2, kcT2, k4c;   // flow slab only
+};
+
+__device__ __forceinline__ KScal make_kscal(const ShootDev& P, double k) {
+  KScal s;
+  s.k = k; s.k2 = k * k; s.m = (double)P.m; s.m2 = s.m * s.m;
+  s.kc2 = s.k2 * P.c2_i; s.kvA2 = s.k2 * P.vA2_i; s.kcT2 = s.k2 * P.cT2_i;
+  s.k4c = s.k2 * s.k2 * P.cT2_i * P.c2_i;
+  return s;
+}
+
+// ---- node entries: everything that depends on (node, k, m) but not on omega ---------------------------------
+template <int FAM>
+__device__ __forceinline__ void make_entry(const double* b, const KScal& s, double* e) {
+  if (FAM == FAM_CYL0) {
+    const double wA = s.k * b[C0_BA];
+    const double wA2 = wA * wA;
+    e[0] = s.k * b[C0_VZ];                     // Doppler shift k v_z
+    e[1] = wA2;                                // omega_A^2
+    e[2] = wA2 * b[C0_Q];                      // omega_c^2 = omega_A^2 c^2/(c^2+vA^2)
+    e[3] = b[C0_A1];                           // rho / r
+    e[4] = b[C0_B1];                           // r / (rho S)
+    e[5] = s.m2 * b[C0_E1] + s.k2 * b[C0_E2];  // (m^2/r^2 + k^2) r / rho
+  } else if (FAM == FAM_CYLT) {
+    const double r = b[CT_R], invr = b[CT_INVR], rho = b[CT_RHO], S = b[CT_S];
+    const double Bphi = b[CT_BPHR] * r, vphi = b[CT_VPHR] * r;
+    const double kb = s.m * b[CT_BPHR] + s.k * b[CT_BZ];        // m B_phi/r + k B_z
+    const double wA = s.m * b[CT_BPHR] + s.k * b[CT_BA];        // as written in the reference (CF:581)
+    const double wA2 = wA * wA;
+    const double invr2 = invr * invr;
+    e[0] = s.m * b[CT_VPHR] + s.k * b[CT_VZ];   // shift: m v_phi/r + k v_z
+    e[1] = wA2;
+    e[2] = wA2 * b[CT_Q];
+    e[3] = rho * S;
+    e[4] = rho;
+    e[5] = rho * vphi * vphi * invr;            // q1
+    e[6] = 2.0 * Bphi * Bphi * invr;            // q2
+    e[7] = 2.0 * Bphi * vphi * kb * invr;       // q3
+    e[8] = kb * Bphi;                           // tt1
+    e[9] = rho * vphi;                          // tt2
+    e[10] = 2.0 * s.m * S * invr2;              // c1c
+    e[11] = S * (s.m2 * invr2 + s.k2);          // c2c
+    e[12] = b[CT_RDC3];                         // r d/dr[(B_phi/r)^2 - rho (v_phi/r)^2]
+    e[13] = 4.0 * S * invr2;                    // c3b
+    e[14] = r;
+    e[15] = invr;
+  } else if (FAM == FAM_SLABD) {
+    const double rho = b[SD_RHO], c2 = b[SD_C2], vA2 = b[SD_VA2];
+    const double S = c2 + vA2;
+    const double cT2 = c2 * vA2 / S;
+    e[0] = s.k2 * c2;
+    e[1] = s.k2 * cT2;
+    e[2] = s.k2 * vA2;
+    e[3] = rho * S;
+    e[4] = rho;
+  } else {
+    e[0] = s.k * b[SF_U];
+    e[1] = s.k * b[SF_DU];
+    e[2] = s.k * b[SF_DDU];
+  }
+}
+
+// sign tracking for the continuum / singular-point flag: bit i of `any1` is set if term i was ever negative,
+// bit i of `any0` if it was ever non-negative; a term that shows both signs crossed zero inside the domain.
+struct SignTrack {
+  unsigned any1 = 0, any0 = 0;
+  __device__ __forceinline__ void add(int i, double t) {
+    const unsigned neg = (t < 0.0) ? 1u : 0u;
+    any1 |= neg << i;
+    any0 |= (neg ^ 1u) << i;
+  }
+  __device__ __forceinline__ bool crossed() const { return (any1 & any0) != 0u; }
+};
+
+template <int FAM>
+__device__ __forceinline__ void coefficients(const double* e, const ShootDev& P, const KScal& s, double w,
+                                             Coef& A, SignTrack& st) {
+  if (FAM == FAM_CYL0) {
+    const double Om = w - e[0];
+    const double Om2 = Om * Om;
+    const double t1 = Om2 - e[1];
+    const double t2 = Om2 - e[2];
+    st.add(0, t1); st.add(1, t2);
+    A.a11 = 0.0; A.a22 = 0.0;
+    A.a12 = e[3] * t1;
+    const double num = e[5] * t2 - e[4] * (Om2 * Om2);
+    A.a21 = num / (t1 * t2);
+  } else if (FAM == FAM_CYLT) {
+    const double Om = w - e[0];
+    const double Om2 = Om * Om;
+    const double t1 = Om2 - e[1];
+    const double t2 = Om2 - e[2];
+    st.add(0, t1); st.add(1, t2);
+    const double D = e[3] * t1 * t2;
+    const double Q = Om2 * e[6] - t1 * e[5] + Om * e[7];
+    const double T = e[8] + e[9] * Om;
+    const double OmP = (P.c1_power == 2) ? Om2 : Om;
+    const double C1 = Q * OmP - e[10] * t2 * T;
+    const double C2 = Om2 * Om2 - e[11] * t2;
+    const double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
+    st.add(2, C3 * D);                       // F = r D / C3 changes sign where C3 does
+    const double invD = 1.0 / D;
+    const double c1d = C1 * invD;
+    A.a11 = -c1d;
+    A.a22 = c1d;
+    A.a12 = C3 * e[15] * invD;
+    A.a21 = -(e[14] * C2) * invD;
+  } else if (FAM == FAM_SLABD) {
+    const double w2 = w * w;
+    const double n1 = e[0] - w2;             // k^2 c^2 - w^2
+    const double n2 = e[1] - w2;             // k^2 cT^2 - w^2
+    const double n3 = e[2] - w2;             // k^2 vA^2 - w^2
+    st.add(0, n1); st.add(1, n2); st.add(2, n3);
+    A.a11 = 0.0; A.a22 = 0.0;
+    A.a12 = n1 / (e[3] * n2);                // 1/F
+    A.a21 = e[4] * n3;                       // F m0
+  } else {
+    const double Om = w - e[0];
+    const double Om2 = Om * Om;
+    const double t = Om2 - s.kcT2;
+    const double n1 = s.kc2 - Om2;
+    const double n3 = s.kvA2 - Om2;
+    st.add(0, n1); st.add(1, t); st.add(2, n3); st.add(3, Om);
+    const double m0 = (n1 * n3) / (P.S_i * (s.kcT2 - Om2));                         // SF-G:416
+    const double Dref = 2.0 * e[1] * (t + s.k4c / (P.S_i * t)) / (Om * (Om2 - s.kc2));   // SF-G:421
+    const double coeff = e[2] / Om + e[1] * Dref / Om - m0;                          // SF-G:427
+    A.a11 = 0.0;
+    A.a12 = 1.0;
+    A.a21 = -coeff;
+    A.a22 = -Dref;
+  }
+}
+
+// ---- one RK4 step of the two-column transfer matrix ----------------------------------------------------------
+template <bool DIAG>
+__device__ __forceinline__ void rk4_step(double& u1, double& v1, double& u2, double& v2, const Coef& A0,
+                                         const Coef& Am, const Coef& A1, double h, double h2, double h6) {
+#define ES_RHS(A, uu, vv, ku, kv)                                              \
+  if (DIAG) { ku = fma(A.a11, uu, A.a12 * vv); kv = fma(A.a22, vv, A.a21 * uu); } \
+  else      { ku = A.a12 * vv;                 kv = A.a21 * uu; }
+  double k1u, k1v, k2u, k2v, k3u, k3v, k4u, k4v, tu, tv;
+  // column 1
+  ES_RHS(A0, u1, v1, k1u, k1v);
+  tu = fma(h2, k1u, u1); tv = fma(h2, k1v, v1);
+  ES_RHS(Am, tu, tv, k2u, k2v);
+  tu = fma(h2, k2u, u1); tv = fma(h2, k2v, v1);
+  ES_RHS(Am, tu, tv, k3u, k3v);
+  tu = fma(h, k3u, u1); tv = fma(h, k3v, v1);
+  ES_RHS(A1, tu, tv, k4u, k4v);
+  u1 = fma(h6, (k1u + k4u) + 2.0 * (k2u + k3u), u1);
+  v1 = fma(h6, (k1v + k4v) + 2.0 * (k2v + k3v), v1);
+  // column 2
+  ES_RHS(A0, u2, v2, k1u, k1v);
+  tu = fma(h2, k1u, u2); tv = fma(h2, k1v, v2);
+  ES_RHS(Am, tu, tv, k2u, k2v);
+  tu = fma(h2, k2u, u2); tv = fma(h2, k2v, v2);
+  ES_RHS(Am, tu, tv, k3u, k3v);
+  tu = fma(h, k3u, u2); tv = fma(h, k3v, v2);
+  ES_RHS(A1, tu, tv, k4u, k4v);
+  u2 = fma(h6, (k1u + k4u) + 2.0 * (k2u + k3u), u2);
+  v2 = fma(h6, (k1v + k4v) + 2.0 * (k2v + k3v), v2);
+#undef ES_RHS
+}
+
+// ---- exterior ------------------------------------------------------------------------------------------------
+struct Exterior {
+  double m_e;       // reference's m_e
+  double cst;       // xi_e_const (cylinder) or p_e_const (slab)
+  double yb, dyb;   // exterior solution and its derivative at the boundary, scaled to |yb| = 1 (sign kept)
+  double Oe;        // Doppler-shifted exterior frequency (slab)
+  int status;       // ES_PT_OK / LEAKY / NONFINITE
+};
+
+__device__ __forceinline__ Exterior exterior_cylinder(const ShootDev& P, double k, double w) {
+  Exterior X;
+  const double k2 = k * k, w2 = w * w;
+  X.Oe = w;
+  X.m_e = ((k2 * P.vAe2 - w2) * (k2 * P.ce2 - w2)) / (P.Se * (k2 * P.cTe2 - w2));     // CF:699
+  X.cst = -1.0 / (P.rho_e * (k2 * P.vAe2 - w2));                                     // CF:702
+  X.yb = X.dyb = NAN;
+  if (X.m_e < 0.0) { X.status = ES_PT_LEAKY; return X; }
+  if (!(X.m_e > 0.0) || !isfinite(X.m_e) || !isfinite(X.cst)) { X.status = ES_PT_NONFINITE; return X; }
+  X.status = ES_PT_OK;
+  const double mu = sqrt(X.m_e);
+  const double sgn = (P.xb < 0.0) ? -1.0 : 1.0;
+  const double xR = mu * (P.R_factor / k), xb = mu;
+  const int n = P.m_ext;
+  double Kb, Kb1, KR, KR1;
+  esb::ke_pair(n, xb, Kb, Kb1);
+  esb::ke_pair(n, xR, KR, KR1);
+  const double dn = (double)n;
+  const double dKb = -Kb1 + (dn / xb) * Kb;          // e^x K_n'(x)
+  const double dKR = -KR1 + (dn / xR) * KR;
+  const double g = P.ic1 / (sgn * mu);
+  // P = a I + b K with (a, b) from the far-field values; common positive factor xR e^{xR - xb} dropped
+  double Pv, dPv;
+  const double gap = xR - xb;
+  if (gap < 40.0) {
+    double Ib, Ib1, IR, IR1;
+    esb::ie_pair(n, xb, Ib, Ib1);
+    esb::ie_pair(n, xR, IR, IR1);
+    const double dIb = Ib1 + (dn / xb) * Ib;         // e^-x I_n'(x)
+    const double dIR = IR1 + (dn / xR) * IR;
+    const double a_s = -(P.ic0 * dKR - g * KR);
+    const double b_s = -(g * IR - P.ic0 * dIR);
+    const double E2 = exp(-2.0 * gap);
+    Pv = b_s * Kb + E2 * a_s * Ib;
+    dPv = sgn * mu * (b_s * dKb + E2 * a_s * dIb);
+  } else {
+    // I-admixture below 1e-34: b ~ (ic0 - g) up to a positive factor (I' ~ I at large argument is NOT assumed:
+    // the sign of b only needs g I - ic0 I', evaluated with the leading asymptotic ratio I'/I = 1 - (1/2x) ...)
+    double IR, IR1;
+    // ratio I_n'/I_n at xR from the uniform large-argument expansion is not needed to machine precision here:
+    // only sign(b) enters (the K-part is normalised away).  Use I'/I = 1 - 1/(2x) - (4n^2-1)/(8x^2).
+    const double rI = 1.0 - 0.5 / xR - (4.0 * dn * dn - 1.0) / (8.0 * xR * xR);
+    (void)IR; (void)IR1;
+    const double b_s = -(g - P.ic0 * rI);
+    Pv = b_s * Kb;
+    dPv = sgn * mu * (b_s * dKb);
+  }
+  const double nrm = fabs(Pv);
+  X.yb = Pv / nrm;
+  X.dyb = dPv / nrm;
+  if (!isfinite(X.yb) || !isfinite(X.dyb)) X.status = ES_PT_NONFINITE;
+  return X;
+}
+
+__device__ __forceinline__ Exterior exterior_slab(const ShootDev& P, double k, double w) {
+  Exterior X;
+  const double k2 = k * k;
+  const double Oe = w - k * P.U_e;
+  const double Oe2 = Oe * Oe;
+  X.Oe = Oe;
+  X.m_e = ((k2 * P.vAe2 - Oe2) * (k2 * P.ce2 - Oe2)) / (P.Se * (k2 * P.cTe2 - Oe2));          // SF-U:542
+  X.cst = P.rho_e * P.Se * (k2 * P.cTe2 - Oe2) / (Oe * (k2 * P.ce2 - Oe2));                   // SF-U:545
+  X.yb = X.dyb = NAN;
+  if (X.m_e < 0.0) { X.status = ES_PT_LEAKY; return X; }
+  if (!(X.m_e > 0.0) || !isfinite(X.m_e) || !isfinite(X.cst)) { X.status = ES_PT_NONFINITE; return X; }
+  X.status = ES_PT_OK;
+  const double mu = sqrt(X.m_e);
+  const double R = P.R_factor / k;
+  const double E2 = exp(-2.0 * mu * (R - 1.0));
+  const double gp = P.ic0 + P.ic1 / mu, gm = P.ic0 - P.ic1 / mu;
+  const double V = gp + E2 * gm;
+  const double dV = mu * (gp - E2 * gm);
+  const double nrm = fabs(V);
+  X.yb = V / nrm;
+  X.dyb = dV / nrm;
+  if (!isfinite(X.yb) || !isfinite(X.dyb)) X.status = ES_PT_NONFINITE;
+  return X;
+}
+
+// ---- boundary algebra ------------------------------------------------------------------------------------------
+// Inputs: transfer matrix columns at the far end (u1, v1) from (1, 0) and (u2, v2) from (0, 1); coefficient set at
+// the first and last node; exterior.  Output: mismatch d = outer - inner and the two terms.
+struct Mismatch { double d, outer, inner; };
+
+template <int FAM>
+__device__ __forceinline__ Mismatch boundary_algebra(const ShootDev& P, const KScal& s, double w, const Exterior& X,
+                                                     double u1, double v1, double u2, double v2,
+                                                     const double* e_first, const Coef& A_last) {
+  Mismatch M;
+  if (FAM == FAM_CYL0 || FAM == FAM_CYLT) {
+    const double Pb = X.yb;
+    const double xi_e = X.cst * X.dyb;                                  // left_xi_solution[-1], CF:775
+    double Xb;
+    if (P.axis_bc == ES_AXIS_KINK) {
+      Xb = (P.bc_const * xi_e - u1 * Pb) / u2;                          // P(r_ax) = B_phi(-1)^2 xi_e, CF:795
+    } else if (P.axis_bc == ES_AXIS_ROTATION_KINK) {
+      Xb = (-(P.bc_const * xi_e) - u1 * Pb) / u2;                       // CR-KF:695-698
+    } else {
+      // sausage: P'(r_ax) = a11 P + a12 Xi = 0 at the last node, CD-C:1082-1085
+      const double al = A_last.a12, be = A_last.a11;
+      Xb = -((al * v1 + be * u1) * Pb) / (al * v2 + be * u2);
+    }
+    const double xi_i = Xb / P.xb;                                      // inside_xi_solution[0], CF:798
+    M.outer = xi_e; M.inner = xi_i; M.d = xi_e - xi_i;
+  } else {
+    const double P_left = X.cst * X.dyb;                                // left_P_solution[-1], SF-U:559
+    if (FAM == FAM_SLABD) {
+      const double Vb = X.yb;                                           // SD-P:473
+      const double sv = (P.slab_sign - u1) * Vb / u2;                   // v(-1) = F Vx'(-1)
+      M.inner = sv / w;                                                 // P_Ti Vx' = (F/w)(sv/F), SD-P:346,495
+    } else {
+      const double Omb = w - e_first[0];                                // w - k U_i(-1)
+      const double Vb = X.yb * Omb / X.Oe;                              // SF-U:558
+      const double sv = (P.slab_sign - u1) * Vb / u2;                   // Vx'(-1)
+      const double Omb2 = Omb * Omb;
+      const double PTi = P.rho_i * P.S_i * (s.kcT2 - Omb2) / (Omb * (s.kc2 - Omb2));   // SF-G:433
+      M.inner = PTi * sv;
+    }
+    M.outer = P_left;
+    M.d = P_left - M.inner;
+  }
+  return M;
+}

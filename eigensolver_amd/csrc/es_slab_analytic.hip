@@ -143,8 +143,8 @@ SlabP to_dev(const es_slab_analytic_params* p) {
 extern "C" int es_slab_analytic_eval(es_context* ctx, const es_slab_analytic_params* p, int mode,
                                      const double* d_K, int nK, const double* d_W, int nW, double* d_D) {
   if (!ctx) return ES_ERR_INVALID_ARG;
-  ES_REQUIRE(ctx, p && d_K && d_W && d_D, "null pointer");
   ES_REQUIRE(ctx, nK >= 0 && nW >= 0, "negative size");
+  ES_REQUIRE(ctx, p && (nK == 0 || nW == 0 || (d_K && d_W && d_D)), "null pointer");
   ES_REQUIRE(ctx, mode >= 0 && mode <= 3, "mode");
   if (nK == 0 || nW == 0) return ES_SUCCESS;
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -164,8 +164,8 @@ extern "C" int es_slab_analytic_scan(es_context* ctx, const es_slab_analytic_par
                                      const double* d_K, int nK, const double* d_W, int nW, double step,
                                      double* d_rootK, double* d_rootW, int capacity, int* h_count) {
   if (!ctx) return ES_ERR_INVALID_ARG;
-  ES_REQUIRE(ctx, p && d_K && d_W && h_count, "null pointer");
   ES_REQUIRE(ctx, nK >= 0 && nW >= 0 && capacity >= 0, "negative size");
+  ES_REQUIRE(ctx, p && h_count && (nK == 0 || nW == 0 || (d_K && d_W)), "null pointer");
   ES_REQUIRE(ctx, capacity == 0 || (d_rootK && d_rootW), "null output with capacity > 0");
   ES_REQUIRE(ctx, mode >= 0 && mode <= 3, "mode");
   *h_count = 0;

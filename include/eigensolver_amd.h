@@ -86,6 +86,92 @@ int es_slab_analytic_filter(es_context* ctx, const es_slab_analytic_params* p, i
                             const double* d_rootK, const double* d_rootW, int n, double thresh,
                             uint8_t* d_keep);
 
+
+/* ========================================================================================================
+ * (2) Shooting evaluation of the boundary determinant D(k, omega) for non-uniform interiors.
+ *     Replaces, per (k, omega), the body of the reference workers (coefficients -> exterior ODE -> interior
+ *     shoot -> mismatch), e.g. Cylinder_method_flow_testing.py:694-804 (kink) / :991-1111 (sausage),
+ *     multiprocessor_Inhomogeneous_method.py:421-501, flow_multiprocessor_coronal.py:400-480,
+ *     Twisted_photospheric_nonlinear_flow_kink_fast.py:601-712.
+ *     D is the reference's mismatch (xi_e - xi_i for cylinders, P_e - P_i for slabs) divided by the exterior
+ *     amplitude |P_e(boundary)| resp. |Vx_e(boundary)|, sign of the reference's amplitude kept.
+ * ====================================================================================================== */
+enum { ES_GEOM_CYLINDER = 0, ES_GEOM_CYLINDER_TWIST = 1, ES_GEOM_SLAB_DENSITY = 2, ES_GEOM_SLAB_FLOW = 3 };
+enum { ES_AXIS_KINK = 0, ES_AXIS_SAUSAGE = 1, ES_AXIS_ROTATION_KINK = 2 };
+enum { ES_SLAB_MODE_SAUSAGE = 0, ES_SLAB_MODE_KINK = 1 };
+enum { ES_W_ABSOLUTE = 0,      /* omega = w[iw]                       (one frequency vector for all k)     */
+       ES_W_PHASE_SPEED = 1,   /* omega = k * w[iw]                   (the reference's bands speeds*k)      */
+       ES_W_PER_ROW = 2 };     /* omega = w[ik * nw + iw]             (one frequency array per task)        */
+
+/* Everything a reference worker captures from module globals. */
+typedef struct es_shoot_desc {
+  int32_t geometry;        /* ES_GEOM_*                                                                   */
+  int32_t n_nodes;         /* interior nodes N: the reference's `ix` grid (linspace(x_b, x_end, N)); the
+                              propagator takes one RK4 step per interval                                    */
+  double x_boundary;       /* first node: -1 (CD-C, CF, slabs) or +1 (CD-P, CR-*)                          */
+  double x_end;            /* last node: -/+ r_axis for cylinders (0.001 / 0.01), +1 for slabs             */
+  /* exterior medium */
+  double rho_e, vA_e, c_e, cT_e, U_e;
+  double L_factor;         /* far field at |x| = L_factor * 2 pi / k   (3 or 7)                             */
+  double ic_value, ic_slope; /* reference's P0 / V0 = [1e-8, 1e-8] or [1e-8, 1e-15]                          */
+  /* cylinder */
+  int32_t m;               /* azimuthal order used in the interior coefficient set                          */
+  int32_t m_ext;           /* order hard-coded in the reference's exterior ODE (1 kink, 0 sausage)          */
+  int32_t axis_bc;         /* ES_AXIS_*                                                                     */
+  int32_t c1_power;        /* C1 = Q*Omega (1: CD-C:590) or Q*Omega^2 (2: CF:598, CR-KF:493)                */
+  double bc_const;         /* kink: B_phi(x_b)^2 ; rotation: B_phi(1)^2 - rho(1) v_phi(1)^2                 */
+  /* slab */
+  int32_t slab_mode;       /* ES_SLAB_MODE_*                                                                */
+  int32_t reserved;
+  double c_i, vA_i, rho_i; /* uniform interior speeds of the flow slab (SF-U / SF-G)                        */
+} es_shoot_desc;
+
+/* Profile samples on the 2N-1 points x_j = x_boundary + j*(x_end - x_boundary)/(2N-2)  (nodes and midpoints),
+ * host pointers, each of length 2N-1; unused ones may be NULL:
+ *   cylinder : r (the x_j themselves), rho, c2 (= c_i^2), Bz, Bphi, vz, vphi, rdC3 (= r d/dr[(Bphi/r)^2 - rho (vphi/r)^2])
+ *   slab dens: rho, c2, vA2
+ *   slab flow: U, dU, ddU                                                                                   */
+typedef struct es_profiles {
+  const double* r; const double* rho; const double* c2; const double* vA2;
+  const double* Bz; const double* Bphi; const double* vz; const double* vphi; const double* rdC3;
+  const double* U; const double* dU; const double* ddU;
+} es_profiles;
+
+int es_problem_create(es_context* ctx, const es_shoot_desc* desc, const es_profiles* h_profiles, es_problem** out);
+int es_problem_destroy(es_context* ctx, es_problem* prob);
+
+/* D[ik*nw + iw], status[ik*nw + iw] (ES_PT_*), optional rel[ik*nw + iw] = 100*|d|/max(|outer|,|inner|)
+ * (the reference's acceptance measure, e.g. Cylinder_method_flow_testing.py:817).  One grid point per lane,
+ * radial-profile coefficients staged in LDS per k-row. */
+int es_shoot_eval_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                       const double* d_w, int nw, int w_mode,
+                       double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
+
+/* The same determinant at n arbitrary (k, omega) pairs (one pair per lane, no shared k). */
+int es_shoot_eval_points(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w, int n,
+                         double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
+
+/* Root table of the grid search (structure of arrays, caller allocated, `capacity` entries each). */
+typedef struct es_root_table {
+  double* d_k;        /* wavenumber of the row                                       */
+  double* d_w;        /* refined omega                                               */
+  double* d_w_lo;     /* bracket [w_lo, w_hi] from the grid                          */
+  double* d_w_hi;
+  double* d_resid;    /* rel = 100 |d| / max(|outer|, |inner|) at the refined omega  */
+  int32_t* d_row;     /* row index ik                                                */
+  uint8_t* d_flag;    /* 1 = accepted root (resid < tol), 0 = sign change at a pole / continuum edge */
+  int32_t capacity;
+} es_root_table;
+
+/* Grid search: brackets = sign changes of D between omega-neighbours of the same row with both ends ES_PT_OK
+ * (wavefront shuffle + ballot, ordered compaction: rows outer, omega inner); each bracket is refined by
+ * `n_bisect` bisection steps (the reference's 3-point linspace refinement, e.g. :823-829, run to convergence)
+ * and classified with the reference's acceptance rule rel < tol_percent.
+ * d_D / d_status must hold the output of es_shoot_eval_grid for the same inputs. */
+int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                        const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,
+                        int n_bisect, double tol_percent, es_root_table* table, int* h_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,426 @@
+/* ORACLE (test infrastructure only; never linked into or called by the product library).
+ *
+ * Plain-C CPU port of the shooting evaluation of the boundary determinant D(k, omega): the same algorithm the HIP
+ * kernels run (closed-form exterior with the reference's far-field initial values, fixed-grid RK4 propagation of
+ * the interior transfer matrix on the reference's `ix` grid, axis / symmetry condition by superposition,
+ * mismatch), written independently in C, operation order fixed (compile with -ffp-contract=off; fused
+ * multiply-adds only through fma()).  It restates, per (k, omega), what the reference workers compute:
+ *   Cylinder/Non-uniform flow/Coronal/solvers/Cylinder_method_flow_testing.py:694-804, :991-1111   (CF)
+ *   Cylinder/Non-uniform density/Coronal/solvers/Density_cylinder.py:694-804, :990-1104            (CD-C)
+ *   Cylinder/Rotational flow/Photospheric/Solvers/Twisted_photospheric_nonlinear_flow_kink_fast.py:601-712 (CR-KF)
+ *   Slab/Non uniform density/Photospheric/Solvers/multiprocessor_Inhomogeneous_method.py:421-501    (SD-P)
+ *   Slab/Non uniform flow/Solver/flow_multiprocessor_coronal.py:400-480, flow_multiprocessor.py:533-586 (SF-G, SF-U)
+ * and the bracket / 3-point-linspace bisection of e.g. CF:823-829 run to convergence on a (k, omega) grid.
+ *
+ * Pinned by tests/test_oracle_port.py against oracle/cylinder.py / oracle/slab.py (DOP853 "truth", themselves
+ * pinned to traces of the reference) and used (a) as the bit-level comparator of the HIP kernels, (b) as the
+ * timed CPU baseline ("port") of bench.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../../include/eigensolver_amd.h"
+
+#define PI 3.14159265358979323846264338327950288
+#define EULER 0.57721566490153286060651209008240243
+
+/* ---- scaled modified Bessel functions (same algorithms as the device header, written independently) -------- */
+static void ke01(double x, double* k0, double* k1) {
+  if (x <= 2.0) {
+    double t = 0.25 * x * x, lg = log(0.5 * x) + EULER;
+    double term0 = 1.0, i0 = 1.0, s0 = 0.0, hk = 0.0, term1 = 1.0, i1 = 1.0, s1 = 1.0;
+    for (int k = 1; k < 40; ++k) {
+      double kk = (double)k;
+      term0 = term0 * t / (kk * kk);
+      hk += 1.0 / kk;
+      i0 += term0;
+      s0 += hk * term0;
+      term1 = term1 * t / (kk * (kk + 1.0));
+      i1 += term1;
+      s1 += (hk + hk + 1.0 / (kk + 1.0)) * term1;
+      if (term0 < 1e-18 * i0) break;
+    }
+    double ex = exp(x);
+    *k0 = ex * (-lg * i0 + s0);
+    *k1 = ex * (1.0 / x + lg * (0.5 * x) * i1 - 0.25 * x * s1);
+  } else {
+    double b = 2.0 * (1.0 + x), d = 1.0 / b, h = d, delh = d, q1 = 0.0, q2 = 1.0;
+    const double a1 = 0.25;
+    double q = a1, c = a1, a = -a1, s = 1.0 + q * delh;
+    for (int i = 2; i < 500; ++i) {
+      a -= 2.0 * (double)(i - 1);
+      c = -a * c / (double)i;
+      double qnew = (q1 - b * q2) / a;
+      q1 = q2; q2 = qnew;
+      q += c * qnew;
+      b += 2.0;
+      d = 1.0 / (b + a * d);
+      delh = (b * d - 1.0) * delh;
+      h += delh;
+      double dels = q * delh;
+      s += dels;
+      if (fabs(dels) < 1e-17 * fabs(s)) break;
+    }
+    h = a1 * h;
+    *k0 = sqrt(PI / (2.0 * x)) / s;
+    *k1 = *k0 * (x + 0.5 - h) / x;
+  }
+}
+static void ke_pair(int n, double x, double* kn, double* kn1) {
+  double a, b;
+  ke01(x, &a, &b);
+  double tox = 2.0 / x;
+  for (int j = 1; j <= n; ++j) { double c = a + (double)j * tox * b; a = b; b = c; }
+  *kn = a; *kn1 = b;
+}
+static void ie_pair(int n, double x, double* in_, double* in1) {
+  double t = 0.25 * x * x, hx = 0.5 * x, pre = 1.0;
+  for (int j = 1; j <= n; ++j) pre *= hx / (double)j;
+  double ta = 1.0, sa = 1.0, tb = 1.0, sb = 1.0;
+  for (int k = 1; k < 400; ++k) {
+    double kk = (double)k;
+    ta = ta * t / (kk * (kk + (double)n));
+    tb = tb * t / (kk * (kk + (double)n + 1.0));
+    sa += ta; sb += tb;
+    if (ta < 1e-18 * sa) break;
+  }
+  double ex = exp(-x);
+  *in_ = ex * pre * sa;
+  *in1 = ex * pre * (hx / ((double)n + 1.0)) * sb;
+}
+
+/* ---- problem ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int family, n_nodes, npts, nb;
+  double xb, h;
+  double* base;
+  double rho_e, vAe2, ce2, cTe2, Se, U_e, R_factor, ic0, ic1;
+  int m, m_ext, axis_bc, c1_power;
+  double bc_const, slab_sign, c2_i, vA2_i, S_i, cT2_i, rho_i;
+} port_problem;
+
+static const int NB_OF[4] = {7, 11, 3, 3};
+static const int NE_OF[4] = {6, 16, 5, 3};
+
+port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
+  port_problem* P = (port_problem*)calloc(1, sizeof(port_problem));
+  int N = d->n_nodes, npts = 2 * N - 1, nb = NB_OF[d->geometry];
+  P->family = d->geometry; P->n_nodes = N; P->npts = npts; P->nb = nb;
+  P->base = (double*)malloc(sizeof(double) * (size_t)nb * npts);
+#define B(f, i) P->base[(size_t)(f) * npts + (i)]
+  for (int i = 0; i < npts; ++i) {
+    if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_CYLINDER_TWIST) {
+      double r = pr->r[i], rho = pr->rho[i], c2 = pr->c2[i], Bz = pr->Bz[i];
+      double Bphi = pr->Bphi ? pr->Bphi[i] : 0.0, vz = pr->vz ? pr->vz[i] : 0.0, vphi = pr->vphi ? pr->vphi[i] : 0.0;
+      double sr = sqrt(rho), bA = Bz / sr, vA = (Bz + Bphi) / sr, S = c2 + vA * vA, q = c2 / S;
+      if (d->geometry == ES_GEOM_CYLINDER) {
+        B(0, i) = vz; B(1, i) = bA; B(2, i) = q; B(3, i) = rho / r; B(4, i) = r / (rho * S);
+        B(5, i) = 1.0 / (r * rho); B(6, i) = r / rho;
+      } else {
+        B(0, i) = r; B(1, i) = 1.0 / r; B(2, i) = rho; B(3, i) = S; B(4, i) = q; B(5, i) = bA; B(6, i) = Bz;
+        B(7, i) = Bphi / r; B(8, i) = vphi / r; B(9, i) = vz; B(10, i) = pr->rdC3 ? pr->rdC3[i] : 0.0;
+      }
+    } else if (d->geometry == ES_GEOM_SLAB_DENSITY) {
+      B(0, i) = pr->rho[i]; B(1, i) = pr->c2[i]; B(2, i) = pr->vA2[i];
+    } else {
+      B(0, i) = pr->U[i]; B(1, i) = pr->dU ? pr->dU[i] : 0.0; B(2, i) = pr->ddU ? pr->ddU[i] : 0.0;
+    }
+  }
+#undef B
+  P->xb = d->x_boundary;
+  P->h = (d->x_end - d->x_boundary) / (double)(N - 1);
+  P->rho_e = d->rho_e; P->vAe2 = d->vA_e * d->vA_e; P->ce2 = d->c_e * d->c_e; P->cTe2 = d->cT_e * d->cT_e;
+  P->Se = P->vAe2 + P->ce2; P->U_e = d->U_e;
+  P->R_factor = d->L_factor * 2.0 * 3.14159265358979323846;
+  P->ic0 = d->ic_value; P->ic1 = d->ic_slope;
+  P->m = d->m; P->m_ext = d->m_ext; P->axis_bc = d->axis_bc; P->c1_power = d->c1_power; P->bc_const = d->bc_const;
+  P->slab_sign = (d->slab_mode == ES_SLAB_MODE_SAUSAGE) ? -1.0 : 1.0;
+  P->c2_i = d->c_i * d->c_i; P->vA2_i = d->vA_i * d->vA_i; P->S_i = P->c2_i + P->vA2_i;
+  P->cT2_i = (P->S_i > 0.0) ? P->c2_i * P->vA2_i / P->S_i : 0.0;
+  P->rho_i = d->rho_i;
+  return P;
+}
+void port_destroy(port_problem* P) { if (P) { free(P->base); free(P); } }
+
+typedef struct { double k, k2, m, m2, kc2, kvA2, kcT2, k4c; } kscal;
+typedef struct { double a11, a12, a21, a22; } coef;
+typedef struct { unsigned any1, any0; } strack;
+static inline void st_add(strack* s, int i, double t) {
+  unsigned neg = (t < 0.0) ? 1u : 0u;
+  s->any1 |= neg << i; s->any0 |= (neg ^ 1u) << i;
+}
+
+static void make_entry(const port_problem* P, int pt, const kscal* s, double* e) {
+  double b[11];
+  for (int f = 0; f < P->nb; ++f) b[f] = P->base[(size_t)f * P->npts + pt];
+  switch (P->family) {
+    case 0: {
+      double wA = s->k * b[1], wA2 = wA * wA;
+      e[0] = s->k * b[0]; e[1] = wA2; e[2] = wA2 * b[2]; e[3] = b[3]; e[4] = b[4];
+      e[5] = s->m2 * b[5] + s->k2 * b[6];
+    } break;
+    case 1: {
+      double r = b[0], invr = b[1], rho = b[2], S = b[3];
+      double Bphi = b[7] * r, vphi = b[8] * r;
+      double kb = s->m * b[7] + s->k * b[6];
+      double wA = s->m * b[7] + s->k * b[5], wA2 = wA * wA, invr2 = invr * invr;
+      e[0] = s->m * b[8] + s->k * b[9]; e[1] = wA2; e[2] = wA2 * b[4]; e[3] = rho * S; e[4] = rho;
+      e[5] = rho * vphi * vphi * invr; e[6] = 2.0 * Bphi * Bphi * invr; e[7] = 2.0 * Bphi * vphi * kb * invr;
+      e[8] = kb * Bphi; e[9] = rho * vphi; e[10] = 2.0 * s->m * S * invr2; e[11] = S * (s->m2 * invr2 + s->k2);
+      e[12] = b[10]; e[13] = 4.0 * S * invr2; e[14] = r; e[15] = invr;
+    } break;
+    case 2: {
+      double rho = b[0], c2 = b[1], vA2 = b[2], S = c2 + vA2, cT2 = c2 * vA2 / S;
+      e[0] = s->k2 * c2; e[1] = s->k2 * cT2; e[2] = s->k2 * vA2; e[3] = rho * S; e[4] = rho;
+    } break;
+    default:
+      e[0] = s->k * b[0]; e[1] = s->k * b[1]; e[2] = s->k * b[2];
+  }
+}
+
+static void coefficients(const port_problem* P, const double* e, const kscal* s, double w, coef* A, strack* st) {
+  switch (P->family) {
+    case 0: {
+      double Om = w - e[0], Om2 = Om * Om, t1 = Om2 - e[1], t2 = Om2 - e[2];
+      st_add(st, 0, t1); st_add(st, 1, t2);
+      A->a11 = 0.0; A->a22 = 0.0;
+      A->a12 = e[3] * t1;
+      double num = e[5] * t2 - e[4] * (Om2 * Om2);
+      A->a21 = num / (t1 * t2);
+    } break;
+    case 1: {
+      double Om = w - e[0], Om2 = Om * Om, t1 = Om2 - e[1], t2 = Om2 - e[2];
+      st_add(st, 0, t1); st_add(st, 1, t2);
+      double D = e[3] * t1 * t2;
+      double Q = Om2 * e[6] - t1 * e[5] + Om * e[7];
+      double T = e[8] + e[9] * Om;
+      double OmP = (P->c1_power == 2) ? Om2 : Om;
+      double C1 = Q * OmP - e[10] * t2 * T;
+      double C2 = Om2 * Om2 - e[11] * t2;
+      double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
+      st_add(st, 2, C3 * D);
+      double invD = 1.0 / D, c1d = C1 * invD;
+      A->a11 = -c1d; A->a22 = c1d; A->a12 = C3 * e[15] * invD; A->a21 = -(e[14] * C2) * invD;
+    } break;
+    case 2: {
+      double w2 = w * w, n1 = e[0] - w2, n2 = e[1] - w2, n3 = e[2] - w2;
+      st_add(st, 0, n1); st_add(st, 1, n2); st_add(st, 2, n3);
+      A->a11 = 0.0; A->a22 = 0.0; A->a12 = n1 / (e[3] * n2); A->a21 = e[4] * n3;
+    } break;
+    default: {
+      double Om = w - e[0], Om2 = Om * Om, t = Om2 - s->kcT2, n1 = s->kc2 - Om2, n3 = s->kvA2 - Om2;
+      st_add(st, 0, n1); st_add(st, 1, t); st_add(st, 2, n3); st_add(st, 3, Om);
+      double m0 = (n1 * n3) / (P->S_i * (s->kcT2 - Om2));
+      double Dref = 2.0 * e[1] * (t + s->k4c / (P->S_i * t)) / (Om * (Om2 - s->kc2));
+      double cf = e[2] / Om + e[1] * Dref / Om - m0;
+      A->a11 = 0.0; A->a12 = 1.0; A->a21 = -cf; A->a22 = -Dref;
+    }
+  }
+}
+
+static inline void rhs(int diag, const coef* A, double u, double v, double* ku, double* kv) {
+  if (diag) { *ku = fma(A->a11, u, A->a12 * v); *kv = fma(A->a22, v, A->a21 * u); }
+  else { *ku = A->a12 * v; *kv = A->a21 * u; }
+}
+static void rk4_col(int diag, double* u, double* v, const coef* A0, const coef* Am, const coef* A1, double h,
+                    double h2, double h6) {
+  double k1u, k1v, k2u, k2v, k3u, k3v, k4u, k4v, tu, tv;
+  rhs(diag, A0, *u, *v, &k1u, &k1v);
+  tu = fma(h2, k1u, *u); tv = fma(h2, k1v, *v);
+  rhs(diag, Am, tu, tv, &k2u, &k2v);
+  tu = fma(h2, k2u, *u); tv = fma(h2, k2v, *v);
+  rhs(diag, Am, tu, tv, &k3u, &k3v);
+  tu = fma(h, k3u, *u); tv = fma(h, k3v, *v);
+  rhs(diag, A1, tu, tv, &k4u, &k4v);
+  *u = fma(h6, (k1u + k4u) + 2.0 * (k2u + k3u), *u);
+  *v = fma(h6, (k1v + k4v) + 2.0 * (k2v + k3v), *v);
+}
+
+typedef struct { double m_e, cst, yb, dyb, Oe; int status; } exterior;
+
+static exterior ext_cyl(const port_problem* P, double k, double w) {
+  exterior X;
+  double k2 = k * k, w2 = w * w;
+  X.Oe = w;
+  X.m_e = ((k2 * P->vAe2 - w2) * (k2 * P->ce2 - w2)) / (P->Se * (k2 * P->cTe2 - w2));
+  X.cst = -1.0 / (P->rho_e * (k2 * P->vAe2 - w2));
+  X.yb = X.dyb = NAN;
+  if (X.m_e < 0.0) { X.status = ES_PT_LEAKY; return X; }
+  if (!(X.m_e > 0.0) || !isfinite(X.m_e) || !isfinite(X.cst)) { X.status = ES_PT_NONFINITE; return X; }
+  X.status = ES_PT_OK;
+  double mu = sqrt(X.m_e), sgn = (P->xb < 0.0) ? -1.0 : 1.0;
+  double xR = mu * (P->R_factor / k), xb = mu;
+  int n = P->m_ext;
+  double Kb, Kb1, KR, KR1, dn = (double)n;
+  ke_pair(n, xb, &Kb, &Kb1);
+  ke_pair(n, xR, &KR, &KR1);
+  double dKb = -Kb1 + (dn / xb) * Kb, dKR = -KR1 + (dn / xR) * KR;
+  double g = P->ic1 / (sgn * mu), Pv, dPv, gap = xR - xb;
+  if (gap < 40.0) {
+    double Ib, Ib1, IR, IR1;
+    ie_pair(n, xb, &Ib, &Ib1);
+    ie_pair(n, xR, &IR, &IR1);
+    double dIb = Ib1 + (dn / xb) * Ib, dIR = IR1 + (dn / xR) * IR;
+    double a_s = -(P->ic0 * dKR - g * KR), b_s = -(g * IR - P->ic0 * dIR), E2 = exp(-2.0 * gap);
+    Pv = b_s * Kb + E2 * a_s * Ib;
+    dPv = sgn * mu * (b_s * dKb + E2 * a_s * dIb);
+  } else {
+    double rI = 1.0 - 0.5 / xR - (4.0 * dn * dn - 1.0) / (8.0 * xR * xR);
+    double b_s = -(g - P->ic0 * rI);
+    Pv = b_s * Kb;
+    dPv = sgn * mu * (b_s * dKb);
+  }
+  double nrm = fabs(Pv);
+  X.yb = Pv / nrm; X.dyb = dPv / nrm;
+  if (!isfinite(X.yb) || !isfinite(X.dyb)) X.status = ES_PT_NONFINITE;
+  return X;
+}
+
+static exterior ext_slab(const port_problem* P, double k, double w) {
+  exterior X;
+  double k2 = k * k, Oe = w - k * P->U_e, Oe2 = Oe * Oe;
+  X.Oe = Oe;
+  X.m_e = ((k2 * P->vAe2 - Oe2) * (k2 * P->ce2 - Oe2)) / (P->Se * (k2 * P->cTe2 - Oe2));
+  X.cst = P->rho_e * P->Se * (k2 * P->cTe2 - Oe2) / (Oe * (k2 * P->ce2 - Oe2));
+  X.yb = X.dyb = NAN;
+  if (X.m_e < 0.0) { X.status = ES_PT_LEAKY; return X; }
+  if (!(X.m_e > 0.0) || !isfinite(X.m_e) || !isfinite(X.cst)) { X.status = ES_PT_NONFINITE; return X; }
+  X.status = ES_PT_OK;
+  double mu = sqrt(X.m_e), R = P->R_factor / k, E2 = exp(-2.0 * mu * (R - 1.0));
+  double gp = P->ic0 + P->ic1 / mu, gm = P->ic0 - P->ic1 / mu;
+  double V = gp + E2 * gm, dV = mu * (gp - E2 * gm), nrm = fabs(V);
+  X.yb = V / nrm; X.dyb = dV / nrm;
+  if (!isfinite(X.yb) || !isfinite(X.dyb)) X.status = ES_PT_NONFINITE;
+  return X;
+}
+
+/* One determinant evaluation.  Returns status; *D, *rel as the product defines them. */
+int port_eval(const port_problem* P, double k, double w, double* D, double* rel) {
+  kscal s;
+  s.k = k; s.k2 = k * k; s.m = (double)P->m; s.m2 = s.m * s.m;
+  s.kc2 = s.k2 * P->c2_i; s.kvA2 = s.k2 * P->vA2_i; s.kcT2 = s.k2 * P->cT2_i;
+  s.k4c = s.k2 * s.k2 * P->cT2_i * P->c2_i;
+  const int diag = (P->family == 1 || P->family == 3);
+  const int nsteps = P->n_nodes - 1;
+  const double h = P->h, h2 = 0.5 * P->h, h6 = P->h / 6.0;
+  double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0, ef[16], e[16];
+  strack trk = {0u, 0u};
+  coef A0, Am, A1;
+  make_entry(P, 0, &s, ef);
+  coefficients(P, ef, &s, w, &A0, &trk);
+  for (int j = 0; j < nsteps; ++j) {
+    make_entry(P, 2 * j + 1, &s, e);
+    coefficients(P, e, &s, w, &Am, &trk);
+    make_entry(P, 2 * j + 2, &s, e);
+    coefficients(P, e, &s, w, &A1, &trk);
+    rk4_col(diag, &u1, &v1, &A0, &Am, &A1, h, h2, h6);
+    rk4_col(diag, &u2, &v2, &A0, &Am, &A1, h, h2, h6);
+    A0 = A1;
+  }
+  exterior X = (P->family <= 1) ? ext_cyl(P, k, w) : ext_slab(P, k, w);
+  double outer, inner;
+  if (P->family <= 1) {
+    double Pb = X.yb, xi_e = X.cst * X.dyb, Xb;
+    if (P->axis_bc == ES_AXIS_KINK) Xb = (P->bc_const * xi_e - u1 * Pb) / u2;
+    else if (P->axis_bc == ES_AXIS_ROTATION_KINK) Xb = (-(P->bc_const * xi_e) - u1 * Pb) / u2;
+    else { double al = A0.a12, be = A0.a11; Xb = -((al * v1 + be * u1) * Pb) / (al * v2 + be * u2); }
+    outer = xi_e; inner = Xb / P->xb;
+  } else {
+    double P_left = X.cst * X.dyb;
+    if (P->family == 2) {
+      double sv = (P->slab_sign - u1) * X.yb / u2;
+      inner = sv / w;
+    } else {
+      double Omb = w - ef[0], Vb = X.yb * Omb / X.Oe, sv = (P->slab_sign - u1) * Vb / u2, Omb2 = Omb * Omb;
+      double PTi = P->rho_i * P->S_i * (s.kcT2 - Omb2) / (Omb * (s.kc2 - Omb2));
+      inner = PTi * sv;
+    }
+    outer = P_left;
+  }
+  double d = outer - inner;
+  int st = X.status;
+  double sc = fmax(fabs(outer), fabs(inner));
+  *D = d;
+  *rel = fabs(d) * 100.0 / sc;
+  if (X.status != ES_PT_OK) { *D = NAN; *rel = NAN; return st; }
+  if (!isfinite(d)) return ES_PT_NONFINITE;
+  if ((trk.any1 & trk.any0) != 0u) st = ES_PT_CONTINUUM;
+  return st;
+}
+
+static double pick_w(const double* wv, int w_mode, double k, long row, int nw, int iw) {
+  if (w_mode == ES_W_PHASE_SPEED) return k * wv[iw];
+  if (w_mode == ES_W_PER_ROW) return wv[row * nw + iw];
+  return wv[iw];
+}
+
+void port_eval_points(const port_problem* P, const double* k, const double* w, long n, double* D, double* rel,
+                      uint8_t* st, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long i = 0; i < n; ++i) {
+    double d, r;
+    st[i] = (uint8_t)port_eval(P, k[i], w[i], &d, &r);
+    D[i] = d;
+    if (rel) rel[i] = r;
+  }
+}
+
+void port_eval_grid(const port_problem* P, const double* k, int nk, const double* w, int nw, int w_mode, double* D,
+                    double* rel, uint8_t* st, int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (long c = 0; c < (long)nk * nw; ++c) {
+    long row = c / nw; int iw = (int)(c - row * nw);
+    double d, r;
+    st[c] = (uint8_t)port_eval(P, k[row], pick_w(w, w_mode, k[row], row, nw, iw), &d, &r);
+    D[c] = d;
+    if (rel) rel[c] = r;
+  }
+}
+
+/* Grid search: brackets (rows outer, omega inner), n_bisect bisection steps, classification. Returns the count. */
+long port_find_roots(const port_problem* P, const double* k, int nk, const double* w, int nw, int w_mode,
+                     const double* D, const uint8_t* st, int n_bisect, double tol, double* out_k, double* out_w,
+                     double* out_lo, double* out_hi, double* out_resid, int32_t* out_row, uint8_t* out_flag,
+                     long capacity, int nthreads) {
+  long count = 0;
+  long* cells = (long*)malloc(sizeof(long) * (size_t)(capacity > 0 ? capacity : 1));
+  for (long row = 0; row < nk; ++row)
+    for (int j = 0; j + 1 < nw; ++j) {
+      long c = row * nw + j;
+      if (st[c] == ES_PT_OK && st[c + 1] == ES_PT_OK && D[c] * D[c + 1] < 0.0) {
+        if (count < capacity) cells[count] = c;
+        ++count;
+      }
+    }
+  long n = count < capacity ? count : capacity;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+  for (long i = 0; i < n; ++i) {
+    long c = cells[i], row = c / nw; int j = (int)(c - row * nw);
+    double kk = k[row], lo = pick_w(w, w_mode, kk, row, nw, j), hi = pick_w(w, w_mode, kk, row, nw, j + 1);
+    double flo = D[c], d, r;
+    for (int it = 0; it < n_bisect; ++it) {
+      double mid = lo + (hi - lo) * 0.5;
+      port_eval(P, kk, mid, &d, &r);
+      if (d * flo < 0.0) hi = mid; else { lo = mid; flo = (d == d) ? d : flo; }
+    }
+    double root = lo + (hi - lo) * 0.5;
+    int s = port_eval(P, kk, root, &d, &r);
+    out_k[i] = kk; out_w[i] = root; out_lo[i] = lo; out_hi[i] = hi; out_resid[i] = r; out_row[i] = (int32_t)row;
+    out_flag[i] = (s == ES_PT_OK && r < tol) ? 1 : 0;
+  }
+  free(cells);
+  return count;
+}

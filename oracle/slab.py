@@ -240,7 +240,9 @@ class SlabProblem:
             return float("nan"), float("nan"), float("nan"), ST_LEAKY
         if not np.isfinite(Vb_e):
             return float("nan"), float("nan"), float("nan"), ST_NONFINITE
-        st = ST_CONTINUUM if self.continuum(k, w) else ST_OK
+        if self.continuum(k, w):
+            return float("nan"), float("nan"), float("nan"), ST_CONTINUUM
+        st = ST_OK
         with np.errstate(all="ignore"):
             xb = np.array([-1.0])
             rho, c2, vA2, S, cT2, Om, m0, F = (v[0] for v in self._coef(xb, k, w))

@@ -1,0 +1,200 @@
+"""GPU parity of the shooting path (K3 grid propagator, K4 bracket + bisection, K5 compaction) through the C ABI
+against the CPU port (same algorithm, oracle/c/shoot_port.c) and the DOP853 oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import cases  # noqa: E402
+
+CASES = cases.all_cases()
+# D agrees with the CPU port to rounding: identical operation order in the propagator; the exterior uses
+# exp/log of two different math libraries (<= 1 ulp each).  Tolerance relative to max(|outer|, |inner|).
+D_RTOL = 1e-12
+ROOT_RTOL = 1e-10          # north star: |d omega / omega| < 1e-10
+
+
+def _gpu_problem(es_ctx, case):
+    from eigensolver_amd import ShootProblem
+    eq, mode, m, _ = case
+    return ShootProblem(eq, mode, m, ctx=es_ctx)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_grid_vs_port(es_ctx, name):
+    case = CASES[name]
+    eq, mode, m, _ = case
+    gp = _gpu_problem(es_ctx, case)
+    port = cases.port_problem(eq, mode, m)
+    k, W = cases.sample_kw(case, nk=7, nw=150, seed=3)
+    D, st, rel = gp.eval_grid(k, W, want_rel=True)
+    D, st, rel = D.cpu().numpy(), st.cpu().numpy(), rel.cpu().numpy()
+    Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=8)
+    assert np.array_equal(st, stp), name
+    ok = st == 0
+    assert ok.sum() > 50, (name, ok.sum())
+    scale = np.abs(Dp[ok]) * 100.0 / relp[ok]                 # max(|outer|, |inner|)
+    err = np.abs(D[ok] - Dp[ok]) / scale
+    assert err.max() < D_RTOL, (name, err.max())
+    # determinant signs bit-exact wherever D is not within rounding of zero
+    big = np.abs(Dp[ok]) > 1e-9 * scale
+    assert np.array_equal(np.signbit(D[ok][big]), np.signbit(Dp[ok][big]))
+    assert np.allclose(rel[ok], relp[ok], rtol=1e-9, atol=1e-12)
+    # flagged lanes carry NaN where the reference skips the point
+    assert np.all(np.isnan(D[(st == 1) | (st == 2)]))
+    gp.close()
+
+
+@pytest.mark.parametrize("name", ["CF_flow_kink", "CR_kink", "SD_w15_kink", "SFG_flow_sausage"])
+def test_points_kernel_equals_grid_kernel(es_ctx, name):
+    """The per-lane path used by the refinement (scalar-loaded base table) and the LDS-staged grid path run the
+    same arithmetic: results must be bit-identical, otherwise brackets and their refinement could disagree."""
+    case = CASES[name]
+    gp = _gpu_problem(es_ctx, case)
+    k, W = cases.sample_kw(case, nk=4, nw=70, seed=5)
+    D, st = gp.eval_grid(k, W)
+    kk = np.repeat(k, len(W))
+    ww = (k[:, None] * W[None, :]).ravel()
+    Dp, stp = gp.eval_points(kk, ww)
+    D, Dp = D.cpu().numpy().ravel(), Dp.cpu().numpy()
+    assert np.array_equal(st.cpu().numpy().ravel(), stp.cpu().numpy())
+    both = ~np.isnan(D)
+    assert np.array_equal(D[both], Dp[both]) and np.array_equal(np.isnan(D), np.isnan(Dp))
+    gp.close()
+
+
+@pytest.mark.parametrize("name", ["CF_flow_kink", "CF_flow_sausage", "CDC_w095_kink", "SD_w15_sausage",
+                                  "SFG_flow_kink"])
+def test_grid_vs_truth_oracle(es_ctx, name):
+    """Against the adaptive DOP853 restatement of the reference ODEs (independent of the RK4 grid)."""
+    case = CASES[name]
+    eq, mode, m, _ = case
+    gp = _gpu_problem(es_ctx, case)
+    truth = cases.truth_problem(eq, mode, m)
+    k, W = cases.sample_kw(case, nk=3, nw=8, seed=11)
+    D, st, rel = gp.eval_grid(k, W, want_rel=True)
+    D, st, rel = D.cpu().numpy(), st.cpu().numpy(), rel.cpu().numpy()
+    n = 0
+    for i, kk in enumerate(k):
+        for j, Wj in enumerate(W):
+            d, a, b, s = truth.mismatch(kk, kk * Wj)
+            if s != 0 or st[i, j] != 0:
+                assert (s == st[i, j]) or 3 in (s, st[i, j])
+                continue
+            n += 1
+            tol = 3e-8 * max(1.0, (1000.0 / eq.n_nodes) ** 4)
+            assert abs(D[i, j] - d) <= tol * max(abs(a), abs(b)), (name, kk, Wj, D[i, j], d)
+    assert n >= 8
+    gp.close()
+
+
+@pytest.mark.parametrize("name", ["CF_flow_kink", "CF_flow_sausage", "CF_uniform_kink", "CDC_w095_kink", "CR_kink",
+                                  "SD_w15_kink", "SFG_flow_kink", "SFU_sausage"])
+def test_roots_vs_port(es_ctx, name):
+    case = CASES[name]
+    eq, mode, m, (lo, hi) = case
+    gp = _gpu_problem(es_ctx, case)
+    port = cases.port_problem(eq, mode, m)
+    k = np.linspace(0.4, 3.9, 24)
+    nw = 192
+    W = lo + (np.arange(nw) + 0.5) * (hi - lo) / nw
+    D, st = gp.eval_grid(k, W)
+    roots, cnt = gp.find_roots(k, W, D, st, n_bisect=44, tol_percent=1e-4)
+    Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=8)
+    assert np.array_equal(st.cpu().numpy(), stp)
+    rp, cntp = port.find_roots(k, W, Dp, stp, w_mode=1, n_bisect=44, tol=1e-4, nthreads=8)
+    assert cnt == cntp, (name, cnt, cntp)
+    assert cnt > 0, name
+    g = {n_: v.cpu().numpy() for n_, v in roots.items()}
+    assert np.array_equal(g["row"], rp["row"]) and np.array_equal(g["k"], rp["k"])
+    assert np.array_equal(g["flag"], rp["flag"]), name
+    acc = g["flag"] == 1
+    assert acc.sum() > 0, name
+    dw = np.abs(g["w"] - rp["w"]) / np.abs(rp["w"])
+    assert dw[acc].max() < ROOT_RTOL, (name, dw[acc].max())
+    # accepted roots lie inside their grid bracket, ordered rows-outer / omega-inner
+    assert np.all(np.diff(g["row"]) >= 0)
+    same = np.diff(g["row"]) == 0
+    assert np.all(np.diff(g["w"])[same] > 0)
+    gp.close()
+
+
+def test_edge_cases(es_ctx):
+    import torch
+    case = CASES["CF_flow_kink"]
+    gp = _gpu_problem(es_ctx, case)
+    # empty inputs
+    D, st = gp.eval_grid(np.zeros(0), np.linspace(3, 4, 5))
+    assert D.shape == (0, 5)
+    D, st = gp.eval_grid([1.0], np.zeros(0))
+    assert D.shape == (1, 0)
+    # ragged widths (not multiples of the wave size) and a single column
+    for nw in (1, 63, 65, 130, 1000, 1025):
+        W = np.linspace(2.8, 4.9, nw)
+        D, st = gp.eval_grid([0.7, 2.2], W)
+        kk = np.repeat([0.7, 2.2], nw)
+        Dp, stp = gp.eval_points(kk, (np.array([0.7, 2.2])[:, None] * W[None, :]).ravel())
+        a, b = D.cpu().numpy().ravel(), Dp.cpu().numpy()
+        assert np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    # leaky (m_e < 0) and singular points are flagged, not evaluated
+    D, st = gp.eval_grid([1.0], [5.5, 5.0, 0.4975185951049946, 3.0], w_mode=1)
+    st = st.cpu().numpy().ravel()
+    assert st[0] == 1 and st[3] == 0
+    assert st[1] in (1, 2) and st[2] in (1, 2)
+    # absolute and per-row frequency modes agree with the phase-speed mode
+    k = np.array([0.9, 1.7])
+    W = np.linspace(2.8, 4.9, 40)
+    D1, _ = gp.eval_grid(k, W, w_mode=1)
+    D2, _ = gp.eval_grid(k, k[:, None] * W[None, :], w_mode=2)
+    assert torch.equal(torch.nan_to_num(D1), torch.nan_to_num(D2))
+    D0, _ = gp.eval_grid([1.7], 1.7 * W, w_mode=0)
+    assert torch.equal(torch.nan_to_num(D0[0]), torch.nan_to_num(D1[1]))
+    # root table capacity smaller than the number of brackets: count reported, first entries identical
+    kk = np.linspace(0.4, 3.9, 40)
+    WW = 2.7 + (np.arange(256) + 0.5) * (4.95 - 2.7) / 256
+    D, st = gp.eval_grid(kk, WW)
+    full, n = gp.find_roots(kk, WW, D, st, n_bisect=30)
+    cut, n2 = gp.find_roots(kk, WW, D, st, n_bisect=30, capacity=3)
+    assert n2 == n and cut["w"].numel() == 3
+    assert torch.equal(cut["w"], full["w"][:3])
+    gp.close()
+
+
+def test_full_size_properties(es_ctx):
+    """BASELINE config 4 size (4096 x 4096, Cylinder / non-uniform flow): size-independent properties."""
+    import torch
+    case = CASES["CF_flow_kink"]
+    eq, mode, m, (lo, hi) = case
+    gp = _gpu_problem(es_ctx, case)
+    n = 4096
+    k = np.linspace(0.01, 4.0, n)
+    W = lo + (np.arange(n) + 0.5) * (hi - lo) / n
+    D, st = gp.eval_grid(k, W)
+    roots, cnt = gp.find_roots(k, W, D, st, n_bisect=40, tol_percent=1e-3, capacity=1 << 18)
+    assert 0 < cnt < (1 << 18)
+    # (a) spot check of the grid against the per-point kernel: bit-identical
+    rng = np.random.default_rng(7)
+    ii, jj = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+    Dp, stp = gp.eval_points(k[ii], k[ii] * W[jj])
+    a = D[torch.as_tensor(ii), torch.as_tensor(jj)].cpu().numpy()
+    b = Dp.cpu().numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    # (b) against the CPU port on the same sample
+    port = cases.port_problem(eq, mode, m)
+    Dc, relc, stc = port.eval_points(k[ii[:600]], k[ii[:600]] * W[jj[:600]], nthreads=8)
+    okc = stc == 0
+    assert np.array_equal(stp.cpu().numpy()[:600], stc)
+    sc = np.abs(Dc[okc]) * 100 / relc[okc]
+    assert (np.abs(b[:600][okc] - Dc[okc]) / sc).max() < D_RTOL
+    # (c) every accepted root sits in a genuine sign change of D and has a tiny residual
+    r = {n_: v.cpu().numpy() for n_, v in roots.items()}
+    acc = r["flag"] == 1
+    assert acc.sum() > 1000
+    assert np.all(r["resid"][acc] < 1e-3)
+    assert np.all((r["w_lo"] <= r["w"]) & (r["w"] <= r["w_hi"]))
+    assert np.all(r["w_hi"][acc] - r["w_lo"][acc] < 1e-9 * np.abs(r["w"][acc]))
+    # (d) ordering and idempotence
+    assert np.all(np.diff(r["row"]) >= 0)
+    roots2, cnt2 = gp.find_roots(k, W, D, st, n_bisect=40, tol_percent=1e-3, capacity=1 << 18)
+    assert cnt2 == cnt and torch.equal(roots2["w"], roots["w"])
+    gp.close()
