@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- det(M) evaluations/s and roots/s of the dispersion-relation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on): Cylinder / non-uniform
+(Gaussian) axial flow, coronal constants of Cylinder_method_flow_testing.py:69-72, 4096 x 4096 (k, omega) grid,
+fp64; k = linspace(0.01, 4, 4096), omega = k * W, W half-cell centred in (cT_i0, vA_e).
+One "step" = one pass of the hot path over that grid on each GPU: D(k, omega) at every grid point (HIP propagator),
+bracket detection (wave shuffle + ballot), bisection refinement, ordered root compaction.
+Multi-GPU: the (k, m) grid tiles across ranks with no data-path collective -- rank r solves azimuthal order
+m = r + 1 on the full (k, omega) grid (weak scaling); the only exchange is one RCCL all-gather of the root tables.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NK = NW = 4096
+W_LO, W_HI = 0.8944271909999159, 5.0          # (cT_i0, vA_e) of the coronal cylinder
+N_BISECT = 26                                 # bracket width 2^-26 * k dW  ->  |d omega/omega| < 1e-10
+TOL_PERCENT = 1e-3
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
+# algorithmic traffic per det-eval of the grid kernel: 8 B D + 1 B status written, inputs amortised
+BYTES_PER_EVAL = 8.0 + 1.0 + 16.0 * (1.0 / NW + 1.0 / NK)
+# fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
+FLOPS_PER_STEP = 2 * 12 + 2 * 28
+
+
+def workload_equilibrium():
+    from eigensolver_amd import equilibrium as q
+    # Gaussian flow of width 0.9 and amplitude 0.35 vA_i0 (CF:126-135 with the author's commented values)
+    return q.CylinderFlow(U_i0=0.7, width=0.9)
+
+
+def cpu_baseline(eq, m, k_np, W_np, target_seconds=12.0):
+    """The oracle's C port (same algorithm, plain C + OpenMP) on a bounded sample of the same workload."""
+    from oracle.port import PortProblem
+    from eigensolver_amd import shooting as s
+    d, p = s.make_desc(eq, "kink", m)
+    port = PortProblem({f[0]: getattr(d, f[0]) for f in d._fields_}, p)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    rows = np.linspace(0, len(k_np) - 1, 8).astype(int)          # calibration: 8 rows spread over the k range
+    t = time.time()
+    port.eval_grid(k_np[rows], W_np, w_mode=1, nthreads=cores)
+    rate = len(rows) * len(W_np) / (time.time() - t)
+    nrows = int(min(len(k_np), max(16, target_seconds * rate / len(W_np))))
+    rows = np.linspace(0, len(k_np) - 1, nrows).astype(int)
+    t = time.time()
+    port.eval_grid(k_np[rows], W_np, w_mode=1, nthreads=cores)
+    dt = time.time() - t
+    return {"value": nrows * len(W_np) / dt, "unit": "det-evals/s", "cores": cores, "kind": "port",
+            "sample": f"{nrows} of {len(k_np)} k-rows x {len(W_np)} omega (same grid, C port oracle/c/shoot_port.c, "
+                      f"OpenMP {cores} threads, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from eigensolver_amd import ShootProblem, _lib
+    from eigensolver_amd.distributed import gather_root_tables
+    dev = torch.device(f"cuda:{local_rank}")
+    ctx = _lib.Context(local_rank)
+    eq = workload_equilibrium()
+    m = rank + 1                                   # rank r owns azimuthal order m = r + 1
+    prob = ShootProblem(eq, "kink", m=m, ctx=ctx)
+    k = torch.linspace(0.01, 4.0, NK, dtype=torch.float64, device=dev)
+    W = W_LO + (torch.arange(NW, dtype=torch.float64, device=dev) + 0.5) * ((W_HI - W_LO) / NW)
+    cap = 1 << 18
+    table = prob.alloc_root_table(cap)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        D, st = prob.eval_grid(k, W)
+        if ev is not None:
+            ev[1].record()
+        roots, nbr = prob.find_roots(k, W, D, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
+        gathered = gather_root_tables(roots, m, world) if world > 1 else None
+        return roots, nbr, gathered
+
+    for _ in range(a.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        roots, nbr, gathered = step(events[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    n_acc = int((roots["flag"] == 1).sum())
+    counts = torch.tensor([float(nbr), float(n_acc)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    brackets_total, roots_total = int(counts[0].item()), int(counts[1].item())
+    grid_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+
+    if rank == 0:
+        evals_per_step = world * NK * NW + brackets_total * (N_BISECT + 1)
+        value = evals_per_step * a.steps / dt
+        grid_evals = NK * NW
+        achieved = grid_evals * BYTES_PER_EVAL / (grid_ms * 1e-3) / 1e9
+        nsteps = eq.n_nodes - 1
+        tflops = grid_evals * FLOPS_PER_STEP * nsteps / (grid_ms * 1e-3) / 1e12
+        out = {
+            "metric": "det(M) evals/sec + roots/sec, 4096x4096 (k,omega) grid",
+            "value": value, "unit": "det-evals/s",
+            "roots_per_s": roots_total * a.steps / dt,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Cylinder / non-uniform (Gaussian) axial flow, coronal, kink-type m = rank+1, "
+                                   "4096x4096 (k,omega) grid per GPU, fp64 (BASELINE.json configs[3])",
+                       "nk": NK, "nw": NW, "interior_nodes": eq.n_nodes, "n_bisect": N_BISECT,
+                       "brackets_per_step": brackets_total, "roots_per_step": roots_total,
+                       "parallelism": f"m-tiled x{world}, one RCCL all-gather of the root table" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "shoot_grid_kernel<FAM_CYL0>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": grid_ms,
+                         "note": "fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
+            "valu_fp64": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                          "flops_per_eval": FLOPS_PER_STEP * nsteps},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eq, m, k.cpu().numpy(), W.cpu().numpy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Multi-GPU tiling of the (k, m) task grid and the one exchange step of the path.
+
+The reference fans (k, band, mode) tasks out to OS processes and pairs two Queues positionally on the way back
+(Density_cylinder.py:1142-1168; latent mis-pairing race).  Here every rank owns a tile of the
+(k, m) grid, produces (k, omega, m, resid, flag) records in one array, and the records are exchanged by a single
+all-gather over RCCL (backend "nccl" on ROCm; "gloo" in the CPU tests): counts first, then the padded tables.
+"""
+import numpy as np
+
+
+def tile_rows(n_rows, rank, world, strided=True):
+    """Row indices (k or task indices) owned by `rank`. Strided tiling balances the k-dependent root density."""
+    if strided:
+        return np.arange(rank, n_rows, world)
+    lo = (n_rows * rank) // world
+    hi = (n_rows * (rank + 1)) // world
+    return np.arange(lo, hi)
+
+
+def tile_modes(m_values, rank, world):
+    """Azimuthal orders owned by `rank` (round-robin)."""
+    return [m for i, m in enumerate(m_values) if i % world == rank]
+
+
+def pack_records(roots, m):
+    """(n, 5) float64 records: k, omega, m, resid, flag -- accepted and rejected brackets alike."""
+    import torch
+    n = roots["w"].numel()
+    rec = torch.empty((n, 5), dtype=torch.float64, device=roots["w"].device)
+    rec[:, 0] = roots["k"]
+    rec[:, 1] = roots["w"]
+    rec[:, 2] = float(m)
+    rec[:, 3] = roots["resid"]
+    rec[:, 4] = roots["flag"].to(torch.float64)
+    return rec
+
+
+def gather_root_tables(roots, m, world=None, group=None):
+    """All-gather the variable-length root tables of all ranks. Returns an (N_total, 5) tensor on every rank,
+    rank-major (deterministic order)."""
+    import torch
+    import torch.distributed as dist
+    rec = pack_records(roots, m)
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return rec
+    n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(max(counts), 1)
+    padded = torch.zeros((nmax, 5), dtype=torch.float64, device=rec.device)
+    padded[:rec.shape[0]] = rec
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded, group=group)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
