@@ -221,9 +221,15 @@ class CylinderProblem:
         return bool(np.any(np.sign(t1) != np.sign(t1[0])) or np.any(np.sign(t2) != np.sign(t2[0])))
 
     # ---- the determinant -----------------------------------------------------------------------------------
-    def mismatch(self, k, w, rtol=1e-12):
-        """Return (d, xi_e, xi_i, status): amplitude-normalised so that |P_e(boundary)| = 1 (sign kept)."""
+    def mismatch(self, k, w, rtol=1e-12, ext_override=None):
+        """Return (d, xi_e, xi_i, status): amplitude-normalised so that |P_e(boundary)| = 1 (sign kept).
+
+        ext_override = (P_b, dP_b): use this exterior end state (e.g. the reference's own LSODA result from a golden
+        trace) instead of the closed form -- isolates the interior part of the comparison."""
         m_e, xi_c, Pb, dPb = self.exterior(k, w)
+        if ext_override is not None and np.isfinite(m_e) and m_e >= 0:
+            a = abs(ext_override[0])
+            Pb, dPb = ext_override[0] / a, ext_override[1] / a
         if np.isfinite(m_e) and m_e < 0.0:
             return float("nan"), float("nan"), float("nan"), ST_LEAKY
         if not np.isfinite(Pb):

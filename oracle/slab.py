@@ -232,10 +232,13 @@ class SlabProblem:
         terms = [k2 * cT2 - Om ** 2, k2 * c2 - Om ** 2, k2 * vA2 - Om ** 2, Om]
         return bool(any(np.any(np.sign(t) != np.sign(t[0])) for t in terms))
 
-    def mismatch(self, k, w, rtol=1e-12):
+    def mismatch(self, k, w, rtol=1e-12, ext_override=None):
         """(d, P_e, P_i, status): left_P_solution[-1] - inside_P_solution[0], normalised to |Vx_e(-1)| = 1."""
         eq = self.eq
         m_e, p_e, Vb_e, dVb_e = self.exterior(k, w)
+        if ext_override is not None and np.isfinite(m_e) and m_e >= 0:
+            a = abs(ext_override[0])
+            Vb_e, dVb_e = ext_override[0] / a, ext_override[1] / a
         if np.isfinite(m_e) and m_e < 0.0:
             return float("nan"), float("nan"), float("nan"), ST_LEAKY
         if not np.isfinite(Vb_e):

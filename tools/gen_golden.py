@@ -80,7 +80,7 @@ CASES = {
     "CDP": ("CD-P", [], [("kink", 2.0, band(0.52, 1.48, 10)), ("sausage", 2.0, band(0.52, 1.48, 10)),
                          ("kink", 0.8, band(0.52, 1.48, 8))]),
     # rotational flow files as checked in
-    "CRKF": ("CR-KF", [], [("kink", 0.3, band(1.255, 1.4, 10)), ("kink", 1.0, band(1.2, 1.45, 10))]),
+    "CRKF": ("CR-KF", [], [("kink", 1.0, band(1.21, 1.44, 10)), ("kink", 2.0, band(1.21, 1.44, 8))]),
     "CRSF": ("CR-SF", [], [("sausage", 1.5, band(1.05, 1.4, 10)), ("sausage", 3.0, band(1.05, 1.4, 8))]),
     "CRKS": ("CR-KS", [], [("kink", 1.0, band(0.7, 0.99, 10))]),
     # slabs
