@@ -139,6 +139,7 @@ class CylinderProblem:
 
         sign(P_b) is the sign of the reference's LSODA amplitude at the boundary (positive initial values)."""
         eq = self.eq
+        k, w = np.float64(k), np.float64(w)          # IEEE semantics (inf/nan, no ZeroDivisionError), as numpy scalars in the reference
         with np.errstate(all="ignore"):
             k2 = k * k
             w2 = w * w

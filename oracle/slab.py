@@ -173,6 +173,7 @@ class SlabProblem:
     def exterior(self, k, w):
         """(m_e, p_e_const, V_b, dV_b), exterior solution scaled to |V_b| = 1 (amplitude sign kept)."""
         eq = self.eq
+        k, w = np.float64(k), np.float64(w)          # IEEE semantics (inf/nan, no ZeroDivisionError), as numpy scalars in the reference
         with np.errstate(all="ignore"):
             Oe = w - k * eq.U_e
             k2 = k * k
