@@ -3,3 +3,5 @@ from ._lib import Context, EsError, load  # noqa: F401
 from .slab_analytic import SlabSteadyFlow  # noqa: F401
 from . import equilibrium  # noqa: F401
 from .shooting import ShootProblem  # noqa: F401
+from .solvers import (CylinderNonUniformDensity, CylinderNonUniformFlow, CylinderRotationalFlow,  # noqa: F401
+                      SlabNonUniformDensity, SlabNonUniformFlow, SlabUniformFlow)

@@ -108,7 +108,7 @@ class ShootDesc(C.Structure):
                 ("U_e", C.c_double), ("L_factor", C.c_double), ("ic_value", C.c_double), ("ic_slope", C.c_double),
                 ("m", C.c_int32), ("m_ext", C.c_int32), ("axis_bc", C.c_int32), ("c1_power", C.c_int32),
                 ("bc_const", C.c_double),
-                ("slab_mode", C.c_int32), ("reserved", C.c_int32),
+                ("slab_mode", C.c_int32), ("accept_norm", C.c_int32),
                 ("c_i", C.c_double), ("vA_i", C.c_double), ("rho_i", C.c_double)]
 
 
@@ -124,6 +124,11 @@ class RootTable(C.Structure):
                 ("d_resid", C.c_void_p), ("d_row", C.c_void_p), ("d_flag", C.c_void_p), ("capacity", C.c_int32)]
 
 
+class WorkerSpec(C.Structure):
+    _fields_ = [("tol_percent", C.c_double), ("min_len", C.c_int32), ("itt_cap", C.c_int32),
+                ("reset_loop_ws_each_iter", C.c_int32), ("break_on_accept", C.c_int32)]
+
+
 def _sig_shoot(lib):
     vp, i, d = C.c_void_p, C.c_int, C.c_double
     lib.es_problem_create.argtypes = [vp, C.POINTER(ShootDesc), C.POINTER(Profiles), C.POINTER(vp)]
@@ -131,6 +136,7 @@ def _sig_shoot(lib):
     lib.es_shoot_eval_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, vp]
     lib.es_shoot_eval_points.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
     lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
+    lib.es_worker_run.argtypes = [vp, vp, C.POINTER(WorkerSpec), vp, i, vp, i, vp, vp, i, vp]
 
 
 _orig_sig = _sig

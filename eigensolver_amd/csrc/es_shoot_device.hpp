@@ -42,6 +42,7 @@ struct ShootDev {
   // slab
   double slab_sign;   // -1 sausage: Vx(+1) = -Vx(-1);  +1 kink
   double c2_i, vA2_i, S_i, cT2_i, rho_i;   // uniform interior speeds of the flow slab
+  int accept_norm;    // 0: rel uses max(|outer|,|inner|); 1: |outer| only (CR-KS:722)
 };
 
 template <int FAM> struct FamTraits;

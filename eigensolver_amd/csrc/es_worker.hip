@@ -1,0 +1,198 @@
+// The reference worker  kink(wavenumber, kink_ws, kink_ks, freq) / sausage(...)  as a device-resident state machine,
+// one task (wavenumber, freq[]) per lane.
+//
+// Restates the main loop and the recursive locate_*() of the workers, e.g.
+//   Cylinder_method_flow_testing.py:556-694 (locate_kink), :702-829 (main loop)   [cylinders: len(ws) > 2]
+//   flow_multiprocessor.py:452-526, :533-625                                       [slabs:     len(ws) > 1]
+//   Twisted_photospheric_nonlinear_flow_kink_fast.py:456-596, :601-734             [break after first accepted point]
+// with the module-global history lists (xi_diff_check, xi_diff_loop_check, all_ws, loop_ws) kept as per-task state
+// for ONE worker call, exactly as a freshly forked reference process sees them.
+//
+// Phase A (es_shoot_eval_grid, called by es_worker_run): D, rel and status at every freq[j] of every task, fully
+// parallel (tasks x nfreq lanes).  Phase B (worker_kernel): the sequential logic; main-loop points are table
+// look-ups, only the refinement points are evaluated.  The recursion of locate_*() becomes an explicit stack of
+// frames {omega[3], kk, itt}; after a child returns the parent continues its loop with the re-bound omega and the
+// incremented itt, as the Python code does.  All lanes of a wave call the determinant evaluation together (lanes
+// without a pending refinement point evaluate a dummy frequency), so the expensive part stays convergent.
+#include "es_shoot_shared.hpp"
+#include <vector>
+
+namespace {
+using namespace es_shoot_shared;
+
+struct Frame {
+  double w0, w1, w2;
+  int kk, itt;
+};
+
+struct WorkerArgs {
+  double tol;
+  int min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept;
+  int ntasks, nfreq, max_roots, stack_depth;
+  const double* k;
+  const double* freq;
+  const double* D;
+  const double* rel;
+  const uint8_t* st;
+  Frame* stack;
+  double* roots;
+  int32_t* nroots;
+  int32_t* nevals;
+};
+
+template <int FAM>
+__global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < a.ntasks;
+  const double k = live ? a.k[t] : 1.0;
+  Frame* stk = a.stack + (size_t)(live ? t : 0) * a.stack_depth;
+  // per-task history (what the reference keeps in module-global lists)
+  int j = 0, sp = 0, nroots = 0, nevals = 0;
+  double main_prev = 0.0, loop_prev = 0.0;           // *_diff_check[-1], *_diff_loop_check[-1] (start [0])
+  int all_len = 0, loop_len = 0;                     // len(all_ws), len(loop_ws)
+  double all_m1 = 0.0, all_m2 = 0.0, loop_m1 = 0.0, loop_m2 = 0.0;   // [-1], [-2]
+  bool done = !live;
+  // hard bound on the work of one task (every loop iteration below consumes one evaluation or pops a frame)
+  const long eval_cap = 3L * (a.itt_cap + 2) * (a.nfreq + 1);
+
+  auto emit = [&](double w) {
+    if (nroots < a.max_roots) a.roots[(size_t)t * a.max_roots + nroots] = w;
+    ++nroots;
+  };
+
+  for (;;) {
+    // ---- advance without evaluating until a refinement point is needed --------------------------------------
+    bool need = false;
+    double w_eval = 1.0;
+    while (!done && !need) {
+      if (sp == 0) {                                              // main loop over freq (CF:702)
+        if (j >= a.nfreq) { done = true; break; }
+        if (a.reset_loop_ws_each_iter) loop_len = 0;              // SF-U:536
+        const size_t o = (size_t)t * a.nfreq + j;
+        const double w = a.freq[o];
+        const uint8_t st = a.st[o];
+        const double d = a.D[o], rel = a.rel[o];
+        ++j;
+        if (st == ES_PT_LEAKY) continue;                          // `if m_e < 0: pass`
+        ++nevals;
+        all_m2 = all_m1; all_m1 = w; ++all_len;                   // all_ws.append(freq[j])
+        const double sign = d * main_prev;                        // sign_check.append(d * check[-2])
+        main_prev = d;
+        if (rel < a.tol) {                                        // CF:817
+          emit(w);
+          all_len = 0;
+          if (a.break_on_accept) done = true;                     // CR-KF:722
+        } else if (sign < 0.0 && all_len > a.min_len) {           // CF:822-829
+          Frame f{all_m2, all_m2 + (all_m1 - all_m2) * 0.5, all_m1, 0, 0};   // np.linspace(all_ws[-2], all_ws[-1], 3)
+          all_len = 0;
+          stk[0] = f;
+          sp = 1;
+        }
+      } else {                                                    // inside locate_*(): top frame
+        Frame& f = stk[sp - 1];
+        if (f.kk >= 3 || f.itt > a.itt_cap) { --sp; continue; }   // loop exhausted / `if itt_num > cap: break`
+        w_eval = (f.kk == 0) ? f.w0 : (f.kk == 1 ? f.w1 : f.w2);
+        need = true;
+      }
+    }
+    if (!__any(need)) break;
+    // ---- one determinant evaluation per lane (dummy for lanes that do not need one) ---------------------------
+    double d, rel; uint8_t st;
+    shoot_point<FAM>(P, k, w_eval, d, rel, st);
+    if (need) {
+      Frame& f = stk[sp - 1];
+      ++f.kk;
+      if ((long)nevals > eval_cap) { sp = 0; done = true; }
+      else if (st != ES_PT_LEAKY) {
+        ++nevals;
+        loop_m2 = loop_m1; loop_m1 = w_eval; ++loop_len;          // loop_ws.append(omega[k])
+        const double sign = d * loop_prev;                        // CF:678
+        loop_prev = d;
+        if (rel < a.tol) {                                        // CF:681-686
+          emit(w_eval);
+          loop_len = 0;
+          --sp;                                                   // break
+        } else if (sign < 0.0 && loop_len > a.min_len) {          // CF:688-694
+          const double lo = loop_m2, hi = loop_m1;
+          f.w0 = lo; f.w1 = lo + (hi - lo) * 0.5; f.w2 = hi;      // omega re-bound in the caller's frame
+          f.itt += 1;
+          loop_len = 0;
+          if (sp < a.stack_depth) {
+            Frame c{f.w0, f.w1, f.w2, 0, f.itt};
+            stk[sp] = c;
+            ++sp;
+          }
+        }
+      }
+    }
+  }
+  if (live) {
+    a.nroots[t] = nroots;
+    if (a.nevals) a.nevals[t] = nevals;
+  }
+}
+
+template <int FAM>
+int launch_worker(es_context* ctx, const es_problem* prob, const WorkerArgs& a) {
+  hipLaunchKernelGGL((worker_kernel<FAM>), dim3((a.ntasks + 63) / 64), dim3(64), 0, ctx->stream, prob->dev, a);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_worker_spec* spec, const double* d_k,
+                             int ntasks, const double* d_freq, int nfreq, double* d_roots, int32_t* d_nroots,
+                             int max_roots, int32_t* d_nevals) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, prob && spec, "null pointer");
+  ES_REQUIRE(ctx, ntasks >= 0 && nfreq >= 0 && max_roots >= 0, "negative size");
+  ES_REQUIRE(ctx, spec->min_len >= 0 && spec->itt_cap >= 0 && spec->itt_cap <= 100000, "worker spec");
+  if (ntasks == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_nroots && (nfreq == 0 || d_freq) && (max_roots == 0 || d_roots), "null pointer");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t cells = (size_t)ntasks * (size_t)(nfreq > 0 ? nfreq : 1);
+  const int depth = spec->itt_cap + 3;
+  double *D = nullptr, *rel = nullptr;
+  uint8_t* st = nullptr;
+  Frame* stack = nullptr;
+  int rc = ES_SUCCESS;
+  // scratch of one call (not on the benchmark path): main-loop table + frame stacks
+  if (hipMalloc(&D, cells * sizeof(double)) != hipSuccess || hipMalloc(&rel, cells * sizeof(double)) != hipSuccess ||
+      hipMalloc(&st, cells) != hipSuccess || hipMalloc(&stack, (size_t)ntasks * depth * sizeof(Frame)) != hipSuccess) {
+    ctx->last_error = "hipMalloc(worker scratch) failed";
+    rc = ES_ERR_HIP;
+  }
+  if (rc == ES_SUCCESS && nfreq > 0)
+    rc = es_shoot_eval_grid(ctx, prob, d_k, ntasks, d_freq, nfreq, ES_W_PER_ROW, D, rel, st);
+  if (rc == ES_SUCCESS) {
+    WorkerArgs a;
+    a.tol = spec->tol_percent; a.min_len = spec->min_len; a.itt_cap = spec->itt_cap;
+    a.reset_loop_ws_each_iter = spec->reset_loop_ws_each_iter; a.break_on_accept = spec->break_on_accept;
+    a.ntasks = ntasks; a.nfreq = nfreq; a.max_roots = max_roots; a.stack_depth = depth;
+    a.k = d_k; a.freq = d_freq; a.D = D; a.rel = rel; a.st = st; a.stack = stack;
+    a.roots = d_roots; a.nroots = d_nroots; a.nevals = d_nevals;
+    switch (prob->dev.family) {
+      case FAM_CYL0: rc = launch_worker<FAM_CYL0>(ctx, prob, a); break;
+      case FAM_CYLT: rc = launch_worker<FAM_CYLT>(ctx, prob, a); break;
+      case FAM_SLABD: rc = launch_worker<FAM_SLABD>(ctx, prob, a); break;
+      case FAM_SLABF: rc = launch_worker<FAM_SLABF>(ctx, prob, a); break;
+      default: rc = ES_ERR_UNSUPPORTED;
+    }
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == ES_SUCCESS) {
+    ctx->last_error = "worker kernel failed";
+    rc = ES_ERR_HIP;
+  }
+  if (D) (void)hipFree(D);
+  if (rel) (void)hipFree(rel);
+  if (st) (void)hipFree(st);
+  if (stack) (void)hipFree(stack);
+  if (rc != ES_SUCCESS) return rc;
+  // capacity check on the host (counts are small)
+  std::vector<int32_t> h((size_t)ntasks);
+  ES_HIP_CHECK(ctx, hipMemcpy(h.data(), d_nroots, (size_t)ntasks * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int t = 0; t < ntasks; ++t)
+    if (h[t] > max_roots) return ES_ERR_CAPACITY;
+  return ES_SUCCESS;
+}

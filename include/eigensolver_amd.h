@@ -122,7 +122,7 @@ typedef struct es_shoot_desc {
   double bc_const;         /* kink: B_phi(x_b)^2 ; rotation: B_phi(1)^2 - rho(1) v_phi(1)^2                 */
   /* slab */
   int32_t slab_mode;       /* ES_SLAB_MODE_*                                                                */
-  int32_t reserved;
+  int32_t accept_norm;     /* 0: rel = 100|d|/max(|outer|,|inner|) (all workers) ; 1: 100|d|/|outer| (CR-KS:722)   */
   double c_i, vA_i, rho_i; /* uniform interior speeds of the flow slab (SF-U / SF-G)                        */
 } es_shoot_desc;
 
@@ -171,6 +171,27 @@ typedef struct es_root_table {
 int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                         const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,
                         int n_bisect, double tol_percent, es_root_table* table, int* h_count);
+
+/* ========================================================================================================
+ * (3) The reference worker itself: kink(wavenumber, kink_ws, kink_ks, freq) / sausage(...) for a batch of
+ *     (wavenumber, freq[]) tasks -- main loop over freq, acceptance test, sign-change detection against the
+ *     previously evaluated point, recursive 3-point refinement locate_*() with all of the reference's
+ *     bookkeeping (e.g. Cylinder_method_flow_testing.py:554-839; quirks listed in DESIGN.md "worker semantics").
+ * ====================================================================================================== */
+typedef struct es_worker_spec {
+  double tol_percent;              /* xi_tol / p_tol / P_tol                                               */
+  int32_t min_len;                 /* refinement needs len(ws) > min_len: 1 slabs (SF-U:518), 2 cylinders (CD-C:680) */
+  int32_t itt_cap;                 /* `if itt_num > cap: break`  (100 ... 500)                              */
+  int32_t reset_loop_ws_each_iter; /* slab sausage workers clear loop_ws at every main iteration (SF-U:536) */
+  int32_t break_on_accept;         /* CR kink workers: `break` after the first accepted grid point (CR-KF:722) */
+} es_worker_spec;
+
+/* Task t: wavenumber d_k[t], frequencies d_freq[t*nfreq .. t*nfreq+nfreq).  Roots of task t are written to
+ * d_roots[t*max_roots ...] in the order the reference appends them; d_nroots[t] is their number (may exceed
+ * max_roots, then ES_ERR_CAPACITY is returned); d_nevals[t] (optional) counts determinant evaluations. */
+int es_worker_run(es_context* ctx, const es_problem* prob, const es_worker_spec* spec,
+                  const double* d_k, int ntasks, const double* d_freq, int nfreq,
+                  double* d_roots, int32_t* d_nroots, int max_roots, int32_t* d_nevals /* may be NULL */);
 
 #ifdef __cplusplus
 }

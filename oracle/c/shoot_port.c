@@ -101,6 +101,7 @@ typedef struct {
   double rho_e, vAe2, ce2, cTe2, Se, U_e, R_factor, ic0, ic1;
   int m, m_ext, axis_bc, c1_power;
   double bc_const, slab_sign, c2_i, vA2_i, S_i, cT2_i, rho_i;
+  int accept_norm;
 } port_problem;
 
 static const int NB_OF[4] = {7, 11, 3, 3};
@@ -142,6 +143,7 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
   P->c2_i = d->c_i * d->c_i; P->vA2_i = d->vA_i * d->vA_i; P->S_i = P->c2_i + P->vA2_i;
   P->cT2_i = (P->S_i > 0.0) ? P->c2_i * P->vA2_i / P->S_i : 0.0;
   P->rho_i = d->rho_i;
+  P->accept_norm = d->accept_norm;
   return P;
 }
 void port_destroy(port_problem* P) { if (P) { free(P->base); free(P); } }
@@ -343,7 +345,7 @@ int port_eval(const port_problem* P, double k, double w, double* D, double* rel)
   }
   double d = outer - inner;
   int st = X.status;
-  double sc = fmax(fabs(outer), fabs(inner));
+  double sc = P->accept_norm ? fabs(outer) : fmax(fabs(outer), fabs(inner));
   *D = d;
   *rel = fabs(d) * 100.0 / sc;
   if (X.status != ES_PT_OK) { *D = NAN; *rel = NAN; return st; }

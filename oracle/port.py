@@ -18,7 +18,7 @@ class ShootDesc(C.Structure):
                 ("U_e", C.c_double), ("L_factor", C.c_double), ("ic_value", C.c_double), ("ic_slope", C.c_double),
                 ("m", C.c_int32), ("m_ext", C.c_int32), ("axis_bc", C.c_int32), ("c1_power", C.c_int32),
                 ("bc_const", C.c_double),
-                ("slab_mode", C.c_int32), ("reserved", C.c_int32),
+                ("slab_mode", C.c_int32), ("accept_norm", C.c_int32),
                 ("c_i", C.c_double), ("vA_i", C.c_double), ("rho_i", C.c_double)]
 
 
