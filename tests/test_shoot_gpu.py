@@ -198,3 +198,21 @@ def test_full_size_properties(es_ctx):
     roots2, cnt2 = gp.find_roots(k, W, D, st, n_bisect=40, tol_percent=1e-3, capacity=1 << 18)
     assert cnt2 == cnt and torch.equal(roots2["w"], roots["w"])
     gp.close()
+
+
+@pytest.mark.parametrize("tag", ["cyl_flow_coronal_noflow", "cyl_density_coronal_w09", "cyl_rot_v01_p1_fund_kink",
+                                 "slab_flow_coronal_w15", "slab_density_coronal_w1e5"])
+def test_gpu_accepts_stored_reference_roots(es_ctx, tag):
+    """Known answers: the roots the reference authors stored (Example data/*.pickle) satisfy the GPU determinant
+    at the tolerance of their worker."""
+    from eigensolver_amd import ShootProblem
+    from tests import stored_sets as S
+    eq, tol, fmin = S.SETS[tag]
+    for mode, w, k in S.pairs(tag):
+        gp = ShootProblem(eq, mode, ctx=es_ctx)
+        D, st, rel = gp.eval_points(k, w, want_rel=True)
+        rel = rel.cpu().numpy()
+        frac = float(np.mean(rel < tol))
+        need = fmin[0] if mode == "sausage" else fmin[1]
+        assert frac >= need, (tag, mode, frac, need)
+        gp.close()
