@@ -28,14 +28,15 @@ sys.path.insert(0, ROOT)
 
 NK = NW = 4096
 W_LO, W_HI = 0.8944271909999159, 5.0          # (cT_i0, vA_e) of the coronal cylinder
-N_BISECT = 26                                 # bracket width 2^-26 * k dW  ->  |d omega/omega| < 1e-10
+N_BISECT = 26                                 # bracket width <= 2^-26 * k dW  ->  |d omega/omega| < 1e-10
+REFINE_ROUNDS = 9                             # 9-section rounds: 9^9 >= 2^26 (8 evaluations per round and bracket)
 TOL_PERCENT = 1e-3
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 # algorithmic traffic per det-eval of the grid kernel: 8 B D + 1 B status written, inputs amortised
 BYTES_PER_EVAL = 8.0 + 1.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-FLOPS_PER_STEP = 2 * 12 + 2 * 28
+FLOPS_PER_STEP = 2 * 10 + 7 + 28            # 2 coefficient sets (10 each) + shared reciprocal (1 div + 6 mul) + one adjoint RK4 column
 
 
 def workload_equilibrium():
@@ -135,7 +136,7 @@ def main():
     grid_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
 
     if rank == 0:
-        evals_per_step = world * NK * NW + brackets_total * (N_BISECT + 1)
+        evals_per_step = world * NK * NW + brackets_total * (8 * REFINE_ROUNDS + 1)
         value = evals_per_step * a.steps / dt
         grid_evals = NK * NW
         achieved = grid_evals * BYTES_PER_EVAL / (grid_ms * 1e-3) / 1e9
@@ -149,7 +150,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Cylinder / non-uniform (Gaussian) axial flow, coronal, kink-type m = rank+1, "
                                    "4096x4096 (k,omega) grid per GPU, fp64 (BASELINE.json configs[3])",
-                       "nk": NK, "nw": NW, "interior_nodes": eq.n_nodes, "n_bisect": N_BISECT,
+                       "nk": NK, "nw": NW, "interior_nodes": eq.n_nodes, "n_bisect": N_BISECT, "refine_rounds_9section": REFINE_ROUNDS,
                        "brackets_per_step": brackets_total, "roots_per_step": roots_total,
                        "parallelism": f"m-tiled x{world}, one RCCL all-gather of the root table" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "shoot_grid_kernel<FAM_CYL0>", "achieved": achieved,

@@ -11,10 +11,11 @@
 //    read with wave-uniform addresses (scalar loads), node entries are formed per lane.  Used for refinement.
 //  * bracket_flag_kernel: sign change against the omega-neighbour through __shfl_down (lane 63 reads the halo
 //    element), ballot masks + per-block counts; bracket_emit_kernel writes the ordered bracket list.
-//  * refine_kernel: one bracket per lane, fixed number of bisection steps (uniform trip count -> no divergence),
-//    final classification with the reference's acceptance measure.
+//  * refine_kernel: 8 lanes per bracket, 9-section rounds steered by a wave ballot (uniform trip count -> no
+//    divergence), final classification with the reference's acceptance measure.
 #include <vector>
 #include <cstdlib>
+#include <cmath>
 
 #include "es_shoot_shared.hpp"
 
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
     for (int w0 = 0; w0 < nw; w0 += T * PTS) {
-      double w[PTS], u1[PTS], v1[PTS], u2[PTS], v2[PTS];
-      Coef A0[PTS];
+      double w[PTS], zp[PTS], zq[PTS];
+      Coef B0[PTS];
       SignTrack trk[PTS];
       bool inr[PTS];
 #pragma unroll
@@ -48,9 +49,11 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
         const int iw = w0 + p * T + (int)threadIdx.x;
         inr[p] = iw < nw;
         w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
-        u1[p] = 1.0; v1[p] = 0.0; u2[p] = 0.0; v2[p] = 1.0;
       }
-      for (int c0 = 0; c0 < nsteps; c0 += CH) {
+      // adjoint march: chunks from the far end of the interior back to the boundary
+      const int nchunks = (nsteps + CH - 1) / CH;
+      for (int c = nchunks - 1; c >= 0; --c) {
+        const int c0 = c * CH;
         const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
         __syncthreads();                               // previous chunk fully consumed
         for (int i = threadIdx.x; i < 2 * nst + 1; i += T) {
@@ -61,31 +64,33 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
           for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = e[f];
         }
         __syncthreads();
-        if (c0 == 0) {
-          double e0[NE];
+        if (c == nchunks - 1) {                        // last node: start vector of the march
+          double eL[NE];
 #pragma unroll
-          for (int f = 0; f < NE; ++f) e0[f] = lds[f * LSTRIDE];
+          for (int f = 0; f < NE; ++f) eL[f] = lds[f * LSTRIDE + 2 * nst];
 #pragma unroll
-          for (int p = 0; p < PTS; ++p) coefficients<FAM>(e0, P, s, w[p], A0[p], trk[p]);
+          for (int p = 0; p < PTS; ++p) {
+            coefficients<FAM>(eL, P, s, w[p], B0[p], trk[p]);
+            adjoint_start(P, B0[p], zp[p], zq[p]);
+          }
         }
-        for (int j = 0; j < nst; ++j) {
+        for (int j = nst - 1; j >= 0; --j) {
           double em[NE], e1[NE];
 #pragma unroll
           for (int f = 0; f < NE; ++f) {
             em[f] = lds[f * LSTRIDE + 2 * j + 1];
-            e1[f] = lds[f * LSTRIDE + 2 * j + 2];
+            e1[f] = lds[f * LSTRIDE + 2 * j];
           }
 #pragma unroll
           for (int p = 0; p < PTS; ++p) {
-            Coef Am, A1;
-            coefficients<FAM>(em, P, s, w[p], Am, trk[p]);
-            coefficients<FAM>(e1, P, s, w[p], A1, trk[p]);
-            rk4_step<DIAG>(u1[p], v1[p], u2[p], v2[p], A0[p], Am, A1, h, h2, h6);
-            A0[p] = A1;
+            Coef Bm, B1;
+            coefficients2<FAM>(em, e1, P, s, w[p], Bm, B1, trk[p]);
+            rk4_step_adjoint<DIAG>(zp[p], zq[p], B0[p], Bm, B1, h, h2, h6);
+            B0[p] = B1;
           }
         }
       }
-      // boundary: exterior closed form + axis / symmetry condition + mismatch
+      // boundary: exterior closed form + far-end condition + mismatch
       double bf[FamTraits<FAM>::NB], ef[NE];
       load_base<FAM>(P, 0, bf);
       make_entry<FAM>(bf, s, ef);
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
         if (!inr[p]) continue;
         const int iw = w0 + p * T + (int)threadIdx.x;
         const Exterior X = exterior_any(P, k, w[p]);
-        const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X, u1[p], v1[p], u2[p], v2[p], ef, A0[p]);
+        const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X, zp[p], zq[p], ef);
         double D, rel; uint8_t st;
         finish_point(P, M, X, trk[p].crossed(), D, rel, st);
         const size_t o = (size_t)row * nw + iw;
@@ -178,26 +183,39 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
   d_lo_sign[pos] = D[c];
 }
 
-// One bracket per lane; n_bisect bisection steps with the midpoint of np.linspace(lo, hi, 3), then classification.
+// Bracket refinement by 9-section: 8 lanes share one bracket (8 brackets per wave).  Per round the 8 lanes
+// evaluate D at the 8 interior points lo + (hi-lo)*(j+1)/9; a ballot collects "sign differs from D(lo)" and the
+// first set bit picks the sub-interval that keeps the sign change next to lo (the one a scan from lo would find,
+// as the reference's left-to-right 3-point refinement does).  n_rounds = ceil(n_bisect * ln2 / ln9) rounds shrink
+// the bracket at least as much as n_bisect bisections would; uniform trip count, no divergence.
 template <int FAM>
-__global__ __launch_bounds__(256) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
-                                                     int n, int n_bisect, double tol_percent) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
+                                                    int n, int n_rounds, double tol_percent) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 3, j = lane & 7;
+  const int i = blockIdx.x * 8 + g;
   const bool in = i < n;
   const double k = in ? tab.d_k[i] : 1.0;
   double lo = in ? tab.d_w_lo[i] : 1.0;
   double hi = in ? tab.d_w_hi[i] : 2.0;
   double flo = in ? d_lo[i] : 1.0;
+  const double frac = (double)(j + 1) / 9.0;
   double D, rel; uint8_t st;
-  for (int it = 0; it < n_bisect; ++it) {
-    const double mid = lo + (hi - lo) * 0.5;
-    shoot_point<FAM>(P, k, mid, D, rel, st);
-    // a non-finite / skipped midpoint keeps the lower end (NaN products compare false, as in the reference)
-    if (D * flo < 0.0) { hi = mid; } else { lo = mid; flo = (D == D) ? D : flo; }
+  for (int it = 0; it < n_rounds; ++it) {
+    const double x = lo + (hi - lo) * frac;
+    shoot_point<FAM>(P, k, x, D, rel, st);
+    const bool diff = (D * flo < 0.0);                 // NaN products compare false, as in the reference
+    const unsigned bits = (unsigned)((__ballot(diff) >> (8 * g)) & 0xFFull);
+    const int first = bits ? (__ffs((int)bits) - 1) : 8;         // first point whose sign differs from D(lo)
+    const int src_hi = (g << 3) + (first < 8 ? first : 7);
+    const int src_lo = (g << 3) + (first > 0 ? first - 1 : 0);
+    const double x_hi = __shfl(x, src_hi), x_lo = __shfl(x, src_lo), d_lo_new = __shfl(D, src_lo);
+    if (first < 8) hi = x_hi;
+    if (first > 0) { lo = x_lo; flo = (d_lo_new == d_lo_new) ? d_lo_new : flo; }
   }
   const double root = lo + (hi - lo) * 0.5;
   shoot_point<FAM>(P, k, root, D, rel, st);
-  if (in) {
+  if (in && j == 0) {
     tab.d_w[i] = root;
     tab.d_w_lo[i] = lo;
     tab.d_w_hi[i] = hi;
@@ -255,8 +273,11 @@ int launch_points(es_context* ctx, const es_problem* prob, const double* d_k, co
 template <int FAM>
 int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const double* d_lo, int n,
                   int n_bisect, double tol) {
-  hipLaunchKernelGGL((refine_kernel<FAM>), dim3((n + 63) / 64), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, n,
-                     n_bisect, tol);
+  // 9-section rounds equivalent to n_bisect halvings: 9^R >= 2^n_bisect
+  int rounds = 0;
+  for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= 9.0) ++rounds;
+  hipLaunchKernelGGL((refine_kernel<FAM>), dim3((n + 7) / 8), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, n,
+                     rounds, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }

@@ -1,6 +1,7 @@
 // Device-side pieces of the shooting evaluation of the boundary determinant D(k, omega):
 //   * per-family coefficient sets of the interior first-order system  y' = A(x; k, omega) y,  y = (u, v)
-//   * the fixed-grid RK4 propagation of the 2x2 transfer matrix from the boundary to the far end of the interior
+//   * the fixed-grid RK4 propagation of ONE row of the 2x2 interior transfer matrix (adjoint march from the far end
+//     of the interior back to the boundary, see rk4_step_adjoint)
 //   * the closed-form exterior solution with the reference's far-field initial values
 //   * the boundary algebra (axis / symmetry condition by superposition, mismatch)
 //
@@ -136,19 +137,25 @@ struct SignTrack {
   __device__ __forceinline__ bool crossed() const { return (any1 & any0) != 0u; }
 };
 
+// Coefficient matrix A(x; k, omega) of one node in two parts: everything except ONE reciprocal.  The entries marked
+// "/den" are numerators; coef_finish() multiplies them with 1/den.  The caller computes the reciprocals of the
+// mid-point and end-point denominators of a step with a single IEEE division: inv = 1/(den_m * den_1),
+// 1/den_m = den_1 * inv, 1/den_1 = den_m * inv  (one v_div sequence per RK4 step instead of two).
+struct CoefPre { double n11, n12, n21, n22, den; };
+
 template <int FAM>
-__device__ __forceinline__ void coefficients(const double* e, const ShootDev& P, const KScal& s, double w,
-                                             Coef& A, SignTrack& st) {
+__device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, const KScal& s, double w, CoefPre& C,
+                                         SignTrack& st) {
   if (FAM == FAM_CYL0) {
     const double Om = w - e[0];
     const double Om2 = Om * Om;
     const double t1 = Om2 - e[1];
     const double t2 = Om2 - e[2];
     st.add(0, t1); st.add(1, t2);
-    A.a11 = 0.0; A.a22 = 0.0;
-    A.a12 = e[3] * t1;
-    const double num = e[5] * t2 - e[4] * (Om2 * Om2);
-    A.a21 = num / (t1 * t2);
+    C.n11 = 0.0; C.n22 = 0.0;
+    C.n12 = e[3] * t1;                                   // rho (Om^2 - wA^2) / r
+    C.n21 = e[5] * t2 - e[4] * (Om2 * Om2);              // -r C2 / (rho S)            /den
+    C.den = t1 * t2;
   } else if (FAM == FAM_CYLT) {
     const double Om = w - e[0];
     const double Om2 = Om * Om;
@@ -162,22 +169,22 @@ __device__ __forceinline__ void coefficients(const double* e, const ShootDev& P,
     const double C1 = Q * OmP - e[10] * t2 * T;
     const double C2 = Om2 * Om2 - e[11] * t2;
     const double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
-    st.add(2, C3 * D);                       // F = r D / C3 changes sign where C3 does
-    const double invD = 1.0 / D;
-    const double c1d = C1 * invD;
-    A.a11 = -c1d;
-    A.a22 = c1d;
-    A.a12 = C3 * e[15] * invD;
-    A.a21 = -(e[14] * C2) * invD;
+    st.add(2, C3 * D);                                   // F = r D / C3 changes sign where C3 does
+    C.n11 = -C1;                                         // all four entries /den
+    C.n22 = C1;
+    C.n12 = C3 * e[15];
+    C.n21 = -(e[14] * C2);
+    C.den = D;
   } else if (FAM == FAM_SLABD) {
     const double w2 = w * w;
-    const double n1 = e[0] - w2;             // k^2 c^2 - w^2
-    const double n2 = e[1] - w2;             // k^2 cT^2 - w^2
-    const double n3 = e[2] - w2;             // k^2 vA^2 - w^2
+    const double n1 = e[0] - w2;                         // k^2 c^2 - w^2
+    const double n2 = e[1] - w2;                         // k^2 cT^2 - w^2
+    const double n3 = e[2] - w2;                         // k^2 vA^2 - w^2
     st.add(0, n1); st.add(1, n2); st.add(2, n3);
-    A.a11 = 0.0; A.a22 = 0.0;
-    A.a12 = n1 / (e[3] * n2);                // 1/F
-    A.a21 = e[4] * n3;                       // F m0
+    C.n11 = 0.0; C.n22 = 0.0;
+    C.n12 = n1;                                          // 1/F = n1 / (rho S n2)      /den
+    C.n21 = e[4] * n3;                                   // F m0
+    C.den = e[3] * n2;
   } else {
     const double Om = w - e[0];
     const double Om2 = Om * Om;
@@ -185,45 +192,83 @@ __device__ __forceinline__ void coefficients(const double* e, const ShootDev& P,
     const double n1 = s.kc2 - Om2;
     const double n3 = s.kvA2 - Om2;
     st.add(0, n1); st.add(1, t); st.add(2, n3); st.add(3, Om);
-    const double m0 = (n1 * n3) / (P.S_i * (s.kcT2 - Om2));                         // SF-G:416
+    const double m0 = (n1 * n3) / (P.S_i * (s.kcT2 - Om2));                              // SF-G:416
     const double Dref = 2.0 * e[1] * (t + s.k4c / (P.S_i * t)) / (Om * (Om2 - s.kc2));   // SF-G:421
-    const double coeff = e[2] / Om + e[1] * Dref / Om - m0;                          // SF-G:427
-    A.a11 = 0.0;
-    A.a12 = 1.0;
-    A.a21 = -coeff;
-    A.a22 = -Dref;
+    const double coeff = e[2] / Om + e[1] * Dref / Om - m0;                              // SF-G:427
+    C.n11 = 0.0;
+    C.n12 = 1.0;
+    C.n21 = -coeff;
+    C.n22 = -Dref;
+    C.den = 1.0;                                         // nothing left to divide
   }
 }
 
-// ---- one RK4 step of the two-column transfer matrix ----------------------------------------------------------
+template <int FAM>
+__device__ __forceinline__ void coef_finish(const CoefPre& C, double inv, Coef& A) {
+  if (FAM == FAM_CYL0) {
+    A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12; A.a21 = C.n21 * inv;
+  } else if (FAM == FAM_CYLT) {
+    A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
+  } else if (FAM == FAM_SLABD) {
+    A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12 * inv; A.a21 = C.n21;
+  } else {
+    A.a11 = C.n11; A.a12 = C.n12; A.a21 = C.n21; A.a22 = C.n22;
+  }
+}
+
+// single node (first node of a traversal): its own division
+template <int FAM>
+__device__ __forceinline__ void coefficients(const double* e, const ShootDev& P, const KScal& s, double w,
+                                             Coef& A, SignTrack& st) {
+  CoefPre C;
+  coef_pre<FAM>(e, P, s, w, C, st);
+  coef_finish<FAM>(C, 1.0 / C.den, A);
+}
+
+// two nodes of one RK4 step (mid-point, end-point) with one division
+template <int FAM>
+__device__ __forceinline__ void coefficients2(const double* em, const double* e1, const ShootDev& P,
+                                              const KScal& s, double w, Coef& Am, Coef& A1, SignTrack& st) {
+  CoefPre Cm, C1;
+  coef_pre<FAM>(em, P, s, w, Cm, st);
+  coef_pre<FAM>(e1, P, s, w, C1, st);
+  const double inv = 1.0 / (Cm.den * C1.den);
+  coef_finish<FAM>(Cm, C1.den * inv, Am);
+  coef_finish<FAM>(C1, Cm.den * inv, A1);
+}
+
+// ---- one RK4 step of the ADJOINT (row-vector) propagation -----------------------------------------------------
+// Only one row of the interior transfer matrix T is needed (the axis / symmetry condition is one linear functional
+// of the state at the far end).  With M the RK4 step matrix from node j to j+1, M^T is the RK4 step of the
+// transposed system taken through the stages in reverse order (A_{j+1}^T, A_{j+1/2}^T, A_j^T), same h.  So the
+// row  r = r_end^T T  is obtained by ONE vector z = (p, q) marched from the far end back to the boundary:
+//      z <- M_j^T z ,   rhs(z) = A^T z = (a11 p + a21 q, a12 p + a22 q).
 template <bool DIAG>
-__device__ __forceinline__ void rk4_step(double& u1, double& v1, double& u2, double& v2, const Coef& A0,
-                                         const Coef& Am, const Coef& A1, double h, double h2, double h6) {
-#define ES_RHS(A, uu, vv, ku, kv)                                              \
-  if (DIAG) { ku = fma(A.a11, uu, A.a12 * vv); kv = fma(A.a22, vv, A.a21 * uu); } \
-  else      { ku = A.a12 * vv;                 kv = A.a21 * uu; }
-  double k1u, k1v, k2u, k2v, k3u, k3v, k4u, k4v, tu, tv;
-  // column 1
-  ES_RHS(A0, u1, v1, k1u, k1v);
-  tu = fma(h2, k1u, u1); tv = fma(h2, k1v, v1);
-  ES_RHS(Am, tu, tv, k2u, k2v);
-  tu = fma(h2, k2u, u1); tv = fma(h2, k2v, v1);
-  ES_RHS(Am, tu, tv, k3u, k3v);
-  tu = fma(h, k3u, u1); tv = fma(h, k3v, v1);
-  ES_RHS(A1, tu, tv, k4u, k4v);
-  u1 = fma(h6, (k1u + k4u) + 2.0 * (k2u + k3u), u1);
-  v1 = fma(h6, (k1v + k4v) + 2.0 * (k2v + k3v), v1);
-  // column 2
-  ES_RHS(A0, u2, v2, k1u, k1v);
-  tu = fma(h2, k1u, u2); tv = fma(h2, k1v, v2);
-  ES_RHS(Am, tu, tv, k2u, k2v);
-  tu = fma(h2, k2u, u2); tv = fma(h2, k2v, v2);
-  ES_RHS(Am, tu, tv, k3u, k3v);
-  tu = fma(h, k3u, u2); tv = fma(h, k3v, v2);
-  ES_RHS(A1, tu, tv, k4u, k4v);
-  u2 = fma(h6, (k1u + k4u) + 2.0 * (k2u + k3u), u2);
-  v2 = fma(h6, (k1v + k4v) + 2.0 * (k2v + k3v), v2);
-#undef ES_RHS
+__device__ __forceinline__ void rk4_step_adjoint(double& p, double& q, const Coef& B0, const Coef& Bm, const Coef& B1,
+                                                 double h, double h2, double h6) {
+#define ES_RHS_T(A, pp, qq, kp, kq)                                              \
+  if (DIAG) { kp = fma(A.a11, pp, A.a21 * qq); kq = fma(A.a22, qq, A.a12 * pp); } \
+  else      { kp = A.a21 * qq;                 kq = A.a12 * pp; }
+  double k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
+  ES_RHS_T(B0, p, q, k1p, k1q);
+  tp = fma(h2, k1p, p); tq = fma(h2, k1q, q);
+  ES_RHS_T(Bm, tp, tq, k2p, k2q);
+  tp = fma(h2, k2p, p); tq = fma(h2, k2q, q);
+  ES_RHS_T(Bm, tp, tq, k3p, k3q);
+  tp = fma(h, k3p, p); tq = fma(h, k3q, q);
+  ES_RHS_T(B1, tp, tq, k4p, k4q);
+  p = fma(h6, (k1p + k4p) + 2.0 * (k2p + k3p), p);
+  q = fma(h6, (k1q + k4q) + 2.0 * (k2q + k3q), q);
+#undef ES_RHS_T
+}
+
+// start vector of the adjoint march: the functional the far-end condition applies to (u, v)
+__device__ __forceinline__ void adjoint_start(const ShootDev& P, const Coef& A_last, double& p, double& q) {
+  if ((P.family == FAM_CYL0 || P.family == FAM_CYLT) && P.axis_bc == ES_AXIS_SAUSAGE) {
+    p = A_last.a11; q = A_last.a12;        // P'(r_ax) = a11 P + a12 Xi = 0   (CD-C:1082-1085)
+  } else {
+    p = 1.0; q = 0.0;                      // P(r_ax) = target (kink) ; Vx(+1) = -/+ Vx(-1) (slabs)
+  }
 }
 
 // ---- exterior ------------------------------------------------------------------------------------------------
@@ -315,27 +360,24 @@ __device__ __forceinline__ Exterior exterior_slab(const ShootDev& P, double k, d
 }
 
 // ---- boundary algebra ------------------------------------------------------------------------------------------
-// Inputs: transfer matrix columns at the far end (u1, v1) from (1, 0) and (u2, v2) from (0, 1); coefficient set at
-// the first and last node; exterior.  Output: mismatch d = outer - inner and the two terms.
+// Inputs: the row r = (r1, r2) of the transfer matrix selected by the far-end condition (r . (u_b, v_b) = target),
+// the node entries of the first node and the exterior.  Output: mismatch d = outer - inner and the two terms.
 struct Mismatch { double d, outer, inner; };
 
 template <int FAM>
 __device__ __forceinline__ Mismatch boundary_algebra(const ShootDev& P, const KScal& s, double w, const Exterior& X,
-                                                     double u1, double v1, double u2, double v2,
-                                                     const double* e_first, const Coef& A_last) {
+                                                     double r1, double r2, const double* e_first) {
   Mismatch M;
   if (FAM == FAM_CYL0 || FAM == FAM_CYLT) {
     const double Pb = X.yb;
     const double xi_e = X.cst * X.dyb;                                  // left_xi_solution[-1], CF:775
     double Xb;
     if (P.axis_bc == ES_AXIS_KINK) {
-      Xb = (P.bc_const * xi_e - u1 * Pb) / u2;                          // P(r_ax) = B_phi(-1)^2 xi_e, CF:795
+      Xb = (P.bc_const * xi_e - r1 * Pb) / r2;                          // P(r_ax) = B_phi(-1)^2 xi_e, CF:795
     } else if (P.axis_bc == ES_AXIS_ROTATION_KINK) {
-      Xb = (-(P.bc_const * xi_e) - u1 * Pb) / u2;                       // CR-KF:695-698
+      Xb = (-(P.bc_const * xi_e) - r1 * Pb) / r2;                       // CR-KF:695-698
     } else {
-      // sausage: P'(r_ax) = a11 P + a12 Xi = 0 at the last node, CD-C:1082-1085
-      const double al = A_last.a12, be = A_last.a11;
-      Xb = -((al * v1 + be * u1) * Pb) / (al * v2 + be * u2);
+      Xb = -(r1 * Pb) / r2;                                             // P'(r_ax) = 0, CD-C:1082-1085
     }
     const double xi_i = Xb / P.xb;                                      // inside_xi_solution[0], CF:798
     M.outer = xi_e; M.inner = xi_i; M.d = xi_e - xi_i;
@@ -343,12 +385,12 @@ __device__ __forceinline__ Mismatch boundary_algebra(const ShootDev& P, const KS
     const double P_left = X.cst * X.dyb;                                // left_P_solution[-1], SF-U:559
     if (FAM == FAM_SLABD) {
       const double Vb = X.yb;                                           // SD-P:473
-      const double sv = (P.slab_sign - u1) * Vb / u2;                   // v(-1) = F Vx'(-1)
+      const double sv = (P.slab_sign - r1) * Vb / r2;                   // v(-1) = F Vx'(-1)
       M.inner = sv / w;                                                 // P_Ti Vx' = (F/w)(sv/F), SD-P:346,495
     } else {
       const double Omb = w - e_first[0];                                // w - k U_i(-1)
       const double Vb = X.yb * Omb / X.Oe;                              // SF-U:558
-      const double sv = (P.slab_sign - u1) * Vb / u2;                   // Vx'(-1)
+      const double sv = (P.slab_sign - r1) * Vb / r2;                   // Vx'(-1)
       const double Omb2 = Omb * Omb;
       const double PTi = P.rho_i * P.S_i * (s.kcT2 - Omb2) / (Omb * (s.kc2 - Omb2));   // SF-G:433
       M.inner = PTi * sv;

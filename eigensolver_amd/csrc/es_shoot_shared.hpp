@@ -52,26 +52,27 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
   const KScal s = make_kscal(P, k);
   const int nsteps = P.n_nodes - 1;
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0;
-  double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0;
   SignTrack trk;
-  double b[NB], ef[NE], e[NE];
-  load_base<FAM>(P, 0, b);
-  make_entry<FAM>(b, s, ef);
-  Coef A0;
-  coefficients<FAM>(ef, P, s, w, A0, trk);
-  for (int j = 0; j < nsteps; ++j) {
-    Coef Am, A1;
+  double b[NB], e[NE], e2[NE];
+  // adjoint march from the last node back to the boundary (same arithmetic as the grid kernel)
+  load_base<FAM>(P, 2 * nsteps, b);
+  make_entry<FAM>(b, s, e);
+  Coef B0;
+  coefficients<FAM>(e, P, s, w, B0, trk);
+  double zp, zq;
+  adjoint_start(P, B0, zp, zq);
+  for (int j = nsteps - 1; j >= 0; --j) {
+    Coef Bm, B1;
     load_base<FAM>(P, 2 * j + 1, b);
     make_entry<FAM>(b, s, e);
-    coefficients<FAM>(e, P, s, w, Am, trk);
-    load_base<FAM>(P, 2 * j + 2, b);
-    make_entry<FAM>(b, s, e);
-    coefficients<FAM>(e, P, s, w, A1, trk);
-    rk4_step<DIAG>(u1, v1, u2, v2, A0, Am, A1, h, h2, h6);
-    A0 = A1;
+    load_base<FAM>(P, 2 * j, b);
+    make_entry<FAM>(b, s, e2);
+    coefficients2<FAM>(e, e2, P, s, w, Bm, B1, trk);
+    rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6);
+    B0 = B1;
   }
   const Exterior X = exterior_any(P, k, w);
-  const Mismatch M = boundary_algebra<FAM>(P, s, w, X, u1, v1, u2, v2, ef, A0);
+  const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
   finish_point(P, M, X, trk.crossed(), D, rel, st);
 }
 

@@ -164,9 +164,11 @@ typedef struct es_root_table {
 } es_root_table;
 
 /* Grid search: brackets = sign changes of D between omega-neighbours of the same row with both ends ES_PT_OK
- * (wavefront shuffle + ballot, ordered compaction: rows outer, omega inner); each bracket is refined by
- * `n_bisect` bisection steps (the reference's 3-point linspace refinement, e.g. :823-829, run to convergence)
- * and classified with the reference's acceptance rule rel < tol_percent.
+ * (wavefront shuffle + ballot, ordered compaction: rows outer, omega inner); each bracket is narrowed at least
+ * as far as `n_bisect` bisection steps would (the reference's 3-point linspace refinement, e.g. :823-829, run to
+ * convergence; executed as ceil(n_bisect*ln2/ln9) rounds of 9-section, 8 lanes per bracket, always keeping the
+ * sign change nearest to the lower end) and classified with the reference's acceptance rule rel < tol_percent.
+ * The root reported is the midpoint of the final bracket.
  * d_D / d_status must hold the output of es_shoot_eval_grid for the same inputs. */
 int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                         const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,

@@ -105,7 +105,6 @@ typedef struct {
 } port_problem;
 
 static const int NB_OF[4] = {7, 11, 3, 3};
-static const int NE_OF[4] = {6, 16, 5, 3};
 
 port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
   port_problem* P = (port_problem*)calloc(1, sizeof(port_problem));
@@ -184,15 +183,18 @@ static void make_entry(const port_problem* P, int pt, const kscal* s, double* e)
   }
 }
 
-static void coefficients(const port_problem* P, const double* e, const kscal* s, double w, coef* A, strack* st) {
+/* numerators and the one denominator of a node's coefficient matrix (see coef_finish) */
+typedef struct { double n11, n12, n21, n22, den; } coefpre;
+
+static void coef_pre(const port_problem* P, const double* e, const kscal* s, double w, coefpre* C, strack* st) {
   switch (P->family) {
     case 0: {
       double Om = w - e[0], Om2 = Om * Om, t1 = Om2 - e[1], t2 = Om2 - e[2];
       st_add(st, 0, t1); st_add(st, 1, t2);
-      A->a11 = 0.0; A->a22 = 0.0;
-      A->a12 = e[3] * t1;
-      double num = e[5] * t2 - e[4] * (Om2 * Om2);
-      A->a21 = num / (t1 * t2);
+      C->n11 = 0.0; C->n22 = 0.0;
+      C->n12 = e[3] * t1;
+      C->n21 = e[5] * t2 - e[4] * (Om2 * Om2);
+      C->den = t1 * t2;
     } break;
     case 1: {
       double Om = w - e[0], Om2 = Om * Om, t1 = Om2 - e[1], t2 = Om2 - e[2];
@@ -205,13 +207,12 @@ static void coefficients(const port_problem* P, const double* e, const kscal* s,
       double C2 = Om2 * Om2 - e[11] * t2;
       double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
       st_add(st, 2, C3 * D);
-      double invD = 1.0 / D, c1d = C1 * invD;
-      A->a11 = -c1d; A->a22 = c1d; A->a12 = C3 * e[15] * invD; A->a21 = -(e[14] * C2) * invD;
+      C->n11 = -C1; C->n22 = C1; C->n12 = C3 * e[15]; C->n21 = -(e[14] * C2); C->den = D;
     } break;
     case 2: {
       double w2 = w * w, n1 = e[0] - w2, n2 = e[1] - w2, n3 = e[2] - w2;
       st_add(st, 0, n1); st_add(st, 1, n2); st_add(st, 2, n3);
-      A->a11 = 0.0; A->a22 = 0.0; A->a12 = n1 / (e[3] * n2); A->a21 = e[4] * n3;
+      C->n11 = 0.0; C->n22 = 0.0; C->n12 = n1; C->n21 = e[4] * n3; C->den = e[3] * n2;
     } break;
     default: {
       double Om = w - e[0], Om2 = Om * Om, t = Om2 - s->kcT2, n1 = s->kc2 - Om2, n3 = s->kvA2 - Om2;
@@ -219,27 +220,54 @@ static void coefficients(const port_problem* P, const double* e, const kscal* s,
       double m0 = (n1 * n3) / (P->S_i * (s->kcT2 - Om2));
       double Dref = 2.0 * e[1] * (t + s->k4c / (P->S_i * t)) / (Om * (Om2 - s->kc2));
       double cf = e[2] / Om + e[1] * Dref / Om - m0;
-      A->a11 = 0.0; A->a12 = 1.0; A->a21 = -cf; A->a22 = -Dref;
+      C->n11 = 0.0; C->n12 = 1.0; C->n21 = -cf; C->n22 = -Dref; C->den = 1.0;
     }
   }
 }
 
-static inline void rhs(int diag, const coef* A, double u, double v, double* ku, double* kv) {
-  if (diag) { *ku = fma(A->a11, u, A->a12 * v); *kv = fma(A->a22, v, A->a21 * u); }
-  else { *ku = A->a12 * v; *kv = A->a21 * u; }
+static void coef_finish(const port_problem* P, const coefpre* C, double inv, coef* A) {
+  switch (P->family) {
+    case 0: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12; A->a21 = C->n21 * inv; break;
+    case 1: A->a11 = C->n11 * inv; A->a22 = C->n22 * inv; A->a12 = C->n12 * inv; A->a21 = C->n21 * inv; break;
+    case 2: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12 * inv; A->a21 = C->n21; break;
+    default: A->a11 = C->n11; A->a12 = C->n12; A->a21 = C->n21; A->a22 = C->n22;
+  }
 }
-static void rk4_col(int diag, double* u, double* v, const coef* A0, const coef* Am, const coef* A1, double h,
-                    double h2, double h6) {
-  double k1u, k1v, k2u, k2v, k3u, k3v, k4u, k4v, tu, tv;
-  rhs(diag, A0, *u, *v, &k1u, &k1v);
-  tu = fma(h2, k1u, *u); tv = fma(h2, k1v, *v);
-  rhs(diag, Am, tu, tv, &k2u, &k2v);
-  tu = fma(h2, k2u, *u); tv = fma(h2, k2v, *v);
-  rhs(diag, Am, tu, tv, &k3u, &k3v);
-  tu = fma(h, k3u, *u); tv = fma(h, k3v, *v);
-  rhs(diag, A1, tu, tv, &k4u, &k4v);
-  *u = fma(h6, (k1u + k4u) + 2.0 * (k2u + k3u), *u);
-  *v = fma(h6, (k1v + k4v) + 2.0 * (k2v + k3v), *v);
+
+static void coefficients(const port_problem* P, const double* e, const kscal* s, double w, coef* A, strack* st) {
+  coefpre C;
+  coef_pre(P, e, s, w, &C, st);
+  coef_finish(P, &C, 1.0 / C.den, A);
+}
+
+/* mid-point and end-point of one step with a single division */
+static void coefficients2(const port_problem* P, const double* em, const double* e1, const kscal* s, double w,
+                          coef* Am, coef* A1, strack* st) {
+  coefpre Cm, C1;
+  coef_pre(P, em, s, w, &Cm, st);
+  coef_pre(P, e1, s, w, &C1, st);
+  double inv = 1.0 / (Cm.den * C1.den);
+  coef_finish(P, &Cm, C1.den * inv, Am);
+  coef_finish(P, &C1, Cm.den * inv, A1);
+}
+
+/* adjoint right-hand side A^T z and one RK4 step of the row-vector march (see rk4_step_adjoint in the HIP header) */
+static inline void rhs_t(int diag, const coef* A, double p, double q, double* kp, double* kq) {
+  if (diag) { *kp = fma(A->a11, p, A->a21 * q); *kq = fma(A->a22, q, A->a12 * p); }
+  else { *kp = A->a21 * q; *kq = A->a12 * p; }
+}
+static void rk4_adjoint(int diag, double* p, double* q, const coef* B0, const coef* Bm, const coef* B1, double h,
+                        double h2, double h6) {
+  double k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
+  rhs_t(diag, B0, *p, *q, &k1p, &k1q);
+  tp = fma(h2, k1p, *p); tq = fma(h2, k1q, *q);
+  rhs_t(diag, Bm, tp, tq, &k2p, &k2q);
+  tp = fma(h2, k2p, *p); tq = fma(h2, k2q, *q);
+  rhs_t(diag, Bm, tp, tq, &k3p, &k3q);
+  tp = fma(h, k3p, *p); tq = fma(h, k3q, *q);
+  rhs_t(diag, B1, tp, tq, &k4p, &k4q);
+  *p = fma(h6, (k1p + k4p) + 2.0 * (k2p + k3p), *p);
+  *q = fma(h6, (k1q + k4q) + 2.0 * (k2q + k3q), *q);
 }
 
 typedef struct { double m_e, cst, yb, dyb, Oe; int status; } exterior;
@@ -309,35 +337,35 @@ int port_eval(const port_problem* P, double k, double w, double* D, double* rel)
   const int diag = (P->family == 1 || P->family == 3);
   const int nsteps = P->n_nodes - 1;
   const double h = P->h, h2 = 0.5 * P->h, h6 = P->h / 6.0;
-  double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0, ef[16], e[16];
+  double e[16], e2[16], zp, zq;
   strack trk = {0u, 0u};
-  coef A0, Am, A1;
-  make_entry(P, 0, &s, ef);
-  coefficients(P, ef, &s, w, &A0, &trk);
-  for (int j = 0; j < nsteps; ++j) {
+  coef B0, Bm, B1;
+  /* adjoint march: one row of the transfer matrix, from the last node back to the boundary */
+  make_entry(P, 2 * nsteps, &s, e);
+  coefficients(P, e, &s, w, &B0, &trk);
+  if (P->family <= 1 && P->axis_bc == ES_AXIS_SAUSAGE) { zp = B0.a11; zq = B0.a12; } else { zp = 1.0; zq = 0.0; }
+  for (int j = nsteps - 1; j >= 0; --j) {
     make_entry(P, 2 * j + 1, &s, e);
-    coefficients(P, e, &s, w, &Am, &trk);
-    make_entry(P, 2 * j + 2, &s, e);
-    coefficients(P, e, &s, w, &A1, &trk);
-    rk4_col(diag, &u1, &v1, &A0, &Am, &A1, h, h2, h6);
-    rk4_col(diag, &u2, &v2, &A0, &Am, &A1, h, h2, h6);
-    A0 = A1;
+    make_entry(P, 2 * j, &s, e2);
+    coefficients2(P, e, e2, &s, w, &Bm, &B1, &trk);
+    rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6);
+    B0 = B1;
   }
   exterior X = (P->family <= 1) ? ext_cyl(P, k, w) : ext_slab(P, k, w);
   double outer, inner;
   if (P->family <= 1) {
     double Pb = X.yb, xi_e = X.cst * X.dyb, Xb;
-    if (P->axis_bc == ES_AXIS_KINK) Xb = (P->bc_const * xi_e - u1 * Pb) / u2;
-    else if (P->axis_bc == ES_AXIS_ROTATION_KINK) Xb = (-(P->bc_const * xi_e) - u1 * Pb) / u2;
-    else { double al = A0.a12, be = A0.a11; Xb = -((al * v1 + be * u1) * Pb) / (al * v2 + be * u2); }
+    if (P->axis_bc == ES_AXIS_KINK) Xb = (P->bc_const * xi_e - zp * Pb) / zq;
+    else if (P->axis_bc == ES_AXIS_ROTATION_KINK) Xb = (-(P->bc_const * xi_e) - zp * Pb) / zq;
+    else Xb = -(zp * Pb) / zq;
     outer = xi_e; inner = Xb / P->xb;
   } else {
     double P_left = X.cst * X.dyb;
     if (P->family == 2) {
-      double sv = (P->slab_sign - u1) * X.yb / u2;
+      double sv = (P->slab_sign - zp) * X.yb / zq;
       inner = sv / w;
     } else {
-      double Omb = w - ef[0], Vb = X.yb * Omb / X.Oe, sv = (P->slab_sign - u1) * Vb / u2, Omb2 = Omb * Omb;
+      double Omb = w - e2[0], Vb = X.yb * Omb / X.Oe, sv = (P->slab_sign - zp) * Vb / zq, Omb2 = Omb * Omb;
       double PTi = P->rho_i * P->S_i * (s.kcT2 - Omb2) / (Omb * (s.kc2 - Omb2));
       inner = PTi * sv;
     }
@@ -405,6 +433,8 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
       }
     }
   long n = count < capacity ? count : capacity;
+  int rounds = 0;
+  for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= 9.0) ++rounds;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -413,10 +443,19 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
     long c = cells[i], row = c / nw; int j = (int)(c - row * nw);
     double kk = k[row], lo = pick_w(w, w_mode, kk, row, nw, j), hi = pick_w(w, w_mode, kk, row, nw, j + 1);
     double flo = D[c], d, r;
-    for (int it = 0; it < n_bisect; ++it) {
-      double mid = lo + (hi - lo) * 0.5;
-      port_eval(P, kk, mid, &d, &r);
-      if (d * flo < 0.0) hi = mid; else { lo = mid; flo = (d == d) ? d : flo; }
+    /* 9-section rounds, as the HIP refine_kernel: points lo + (hi-lo)*(j+1)/9, first sign change from the left */
+    for (int it = 0; it < rounds; ++it) {
+      double x[8], dv[8];
+      int first = 8;
+      for (int j = 0; j < 8; ++j) {
+        x[j] = lo + (hi - lo) * ((double)(j + 1) / 9.0);
+        port_eval(P, kk, x[j], &dv[j], &r);
+      }
+      for (int j = 0; j < 8; ++j) if (dv[j] * flo < 0.0) { first = j; break; }
+      double nlo = lo, nflo = flo;
+      if (first > 0) { nlo = x[first - 1]; nflo = (dv[first - 1] == dv[first - 1]) ? dv[first - 1] : flo; }
+      if (first < 8) hi = x[first];
+      lo = nlo; flo = nflo;
     }
     double root = lo + (hi - lo) * 0.5;
     int s = port_eval(P, kk, root, &d, &r);
