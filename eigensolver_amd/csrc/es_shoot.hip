@@ -34,7 +34,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
   __shared__ double lds[NE * LSTRIDE];
   const int T = blockDim.x;
   const int nsteps = P.n_nodes - 1;
-  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0;
+  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
 
   for (int row = blockIdx.x; row < nk; row += gridDim.x) {
     const double k = kv[row];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
           for (int p = 0; p < PTS; ++p) {
             Coef Bm, B1;
             coefficients2<FAM>(em, e1, P, s, w[p], Bm, B1, trk[p]);
-            rk4_step_adjoint<DIAG>(zp[p], zq[p], B0[p], Bm, B1, h, h2, h6);
+            rk4_step_adjoint<DIAG>(zp[p], zq[p], B0[p], Bm, B1, h, h2, h6, h3);
             B0[p] = B1;
           }
         }

@@ -125,16 +125,22 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
   }
 }
 
-// sign tracking for the continuum / singular-point flag: bit i of `any1` is set if term i was ever negative,
-// bit i of `any0` if it was ever non-negative; a term that shows both signs crossed zero inside the domain.
+// sign tracking for the continuum / singular-point flag: the IEEE sign bits (high dwords) of every watched term are
+// OR-ed and AND-ed over all nodes with 32-bit integer ops (cheaper than fp64 compares in the hot loop); a term
+// whose OR has the sign bit set while its AND has not took both signs, i.e. crossed zero inside the domain.
 struct SignTrack {
-  unsigned any1 = 0, any0 = 0;
+  int any_or[4] = {0, 0, 0, 0};
+  int any_and[4] = {-1, -1, -1, -1};
   __device__ __forceinline__ void add(int i, double t) {
-    const unsigned neg = (t < 0.0) ? 1u : 0u;
-    any1 |= neg << i;
-    any0 |= (neg ^ 1u) << i;
+    const int hi = __double2hiint(t);
+    any_or[i] |= hi;
+    any_and[i] &= hi;
   }
-  __device__ __forceinline__ bool crossed() const { return (any1 & any0) != 0u; }
+  __device__ __forceinline__ bool crossed() const {
+    // sign bit set in the OR (some node negative) and clear in the AND (some node non-negative); unused terms: 0
+    return (((any_or[0] & ~any_and[0]) | (any_or[1] & ~any_and[1]) | (any_or[2] & ~any_and[2]) |
+             (any_or[3] & ~any_and[3])) < 0);
+  }
 };
 
 // Coefficient matrix A(x; k, omega) of one node in two parts: everything except ONE reciprocal.  The entries marked
@@ -154,7 +160,7 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     st.add(0, t1); st.add(1, t2);
     C.n11 = 0.0; C.n22 = 0.0;
     C.n12 = e[3] * t1;                                   // rho (Om^2 - wA^2) / r
-    C.n21 = e[5] * t2 - e[4] * (Om2 * Om2);              // -r C2 / (rho S)            /den
+    C.n21 = fma(e[5], t2, -(e[4] * (Om2 * Om2)));        // -r C2 / (rho S)            /den
     C.den = t1 * t2;
   } else if (FAM == FAM_CYLT) {
     const double Om = w - e[0];
@@ -245,7 +251,7 @@ __device__ __forceinline__ void coefficients2(const double* em, const double* e1
 //      z <- M_j^T z ,   rhs(z) = A^T z = (a11 p + a21 q, a12 p + a22 q).
 template <bool DIAG>
 __device__ __forceinline__ void rk4_step_adjoint(double& p, double& q, const Coef& B0, const Coef& Bm, const Coef& B1,
-                                                 double h, double h2, double h6) {
+                                                 double h, double h2, double h6, double h3) {
 #define ES_RHS_T(A, pp, qq, kp, kq)                                              \
   if (DIAG) { kp = fma(A.a11, pp, A.a21 * qq); kq = fma(A.a22, qq, A.a12 * pp); } \
   else      { kp = A.a21 * qq;                 kq = A.a12 * pp; }
@@ -257,8 +263,8 @@ __device__ __forceinline__ void rk4_step_adjoint(double& p, double& q, const Coe
   ES_RHS_T(Bm, tp, tq, k3p, k3q);
   tp = fma(h, k3p, p); tq = fma(h, k3q, q);
   ES_RHS_T(B1, tp, tq, k4p, k4q);
-  p = fma(h6, (k1p + k4p) + 2.0 * (k2p + k3p), p);
-  q = fma(h6, (k1q + k4q) + 2.0 * (k2q + k3q), q);
+  p = fma(h6, k1p + k4p, fma(h3, k2p + k3p, p));         // p + h/6 (k1 + k4) + h/3 (k2 + k3)
+  q = fma(h6, k1q + k4q, fma(h3, k2q + k3q, q));
 #undef ES_RHS_T
 }
 

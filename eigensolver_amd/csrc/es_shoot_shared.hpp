@@ -51,7 +51,7 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
   constexpr bool DIAG = FamTraits<FAM>::DIAG;
   const KScal s = make_kscal(P, k);
   const int nsteps = P.n_nodes - 1;
-  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0;
+  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
   SignTrack trk;
   double b[NB], e[NE], e2[NE];
   // adjoint march from the last node back to the boundary (same arithmetic as the grid kernel)
@@ -68,7 +68,7 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
     load_base<FAM>(P, 2 * j, b);
     make_entry<FAM>(b, s, e2);
     coefficients2<FAM>(e, e2, P, s, w, Bm, B1, trk);
-    rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6);
+    rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
     B0 = B1;
   }
   const Exterior X = exterior_any(P, k, w);

@@ -149,10 +149,16 @@ void port_destroy(port_problem* P) { if (P) { free(P->base); free(P); } }
 
 typedef struct { double k, k2, m, m2, kc2, kvA2, kcT2, k4c; } kscal;
 typedef struct { double a11, a12, a21, a22; } coef;
-typedef struct { unsigned any1, any0; } strack;
+/* IEEE sign bits of the watched terms OR-ed / AND-ed over all nodes (same bookkeeping as the HIP SignTrack) */
+typedef struct { int32_t any_or[4], any_and[4]; } strack;
 static inline void st_add(strack* s, int i, double t) {
-  unsigned neg = (t < 0.0) ? 1u : 0u;
-  s->any1 |= neg << i; s->any0 |= (neg ^ 1u) << i;
+  uint64_t u; memcpy(&u, &t, 8);
+  int32_t hi = (int32_t)(u >> 32);
+  s->any_or[i] |= hi; s->any_and[i] &= hi;
+}
+static inline int st_crossed(const strack* s) {
+  return (((s->any_or[0] & ~s->any_and[0]) | (s->any_or[1] & ~s->any_and[1]) | (s->any_or[2] & ~s->any_and[2]) |
+           (s->any_or[3] & ~s->any_and[3])) < 0);
 }
 
 static void make_entry(const port_problem* P, int pt, const kscal* s, double* e) {
@@ -193,7 +199,7 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
       st_add(st, 0, t1); st_add(st, 1, t2);
       C->n11 = 0.0; C->n22 = 0.0;
       C->n12 = e[3] * t1;
-      C->n21 = e[5] * t2 - e[4] * (Om2 * Om2);
+      C->n21 = fma(e[5], t2, -(e[4] * (Om2 * Om2)));
       C->den = t1 * t2;
     } break;
     case 1: {
@@ -257,7 +263,7 @@ static inline void rhs_t(int diag, const coef* A, double p, double q, double* kp
   else { *kp = A->a21 * q; *kq = A->a12 * p; }
 }
 static void rk4_adjoint(int diag, double* p, double* q, const coef* B0, const coef* Bm, const coef* B1, double h,
-                        double h2, double h6) {
+                        double h2, double h6, double h3) {
   double k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
   rhs_t(diag, B0, *p, *q, &k1p, &k1q);
   tp = fma(h2, k1p, *p); tq = fma(h2, k1q, *q);
@@ -266,8 +272,8 @@ static void rk4_adjoint(int diag, double* p, double* q, const coef* B0, const co
   rhs_t(diag, Bm, tp, tq, &k3p, &k3q);
   tp = fma(h, k3p, *p); tq = fma(h, k3q, *q);
   rhs_t(diag, B1, tp, tq, &k4p, &k4q);
-  *p = fma(h6, (k1p + k4p) + 2.0 * (k2p + k3p), *p);
-  *q = fma(h6, (k1q + k4q) + 2.0 * (k2q + k3q), *q);
+  *p = fma(h6, k1p + k4p, fma(h3, k2p + k3p, *p));
+  *q = fma(h6, k1q + k4q, fma(h3, k2q + k3q, *q));
 }
 
 typedef struct { double m_e, cst, yb, dyb, Oe; int status; } exterior;
@@ -336,9 +342,9 @@ int port_eval(const port_problem* P, double k, double w, double* D, double* rel)
   s.k4c = s.k2 * s.k2 * P->cT2_i * P->c2_i;
   const int diag = (P->family == 1 || P->family == 3);
   const int nsteps = P->n_nodes - 1;
-  const double h = P->h, h2 = 0.5 * P->h, h6 = P->h / 6.0;
+  const double h = P->h, h2 = 0.5 * P->h, h6 = P->h / 6.0, h3 = P->h / 3.0;
   double e[16], e2[16], zp, zq;
-  strack trk = {0u, 0u};
+  strack trk = {{0, 0, 0, 0}, {-1, -1, -1, -1}};
   coef B0, Bm, B1;
   /* adjoint march: one row of the transfer matrix, from the last node back to the boundary */
   make_entry(P, 2 * nsteps, &s, e);
@@ -348,7 +354,7 @@ int port_eval(const port_problem* P, double k, double w, double* D, double* rel)
     make_entry(P, 2 * j + 1, &s, e);
     make_entry(P, 2 * j, &s, e2);
     coefficients2(P, e, e2, &s, w, &Bm, &B1, &trk);
-    rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6);
+    rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
     B0 = B1;
   }
   exterior X = (P->family <= 1) ? ext_cyl(P, k, w) : ext_slab(P, k, w);
@@ -378,7 +384,7 @@ int port_eval(const port_problem* P, double k, double w, double* D, double* rel)
   *rel = fabs(d) * 100.0 / sc;
   if (X.status != ES_PT_OK) { *D = NAN; *rel = NAN; return st; }
   if (!isfinite(d)) return ES_PT_NONFINITE;
-  if ((trk.any1 & trk.any0) != 0u) st = ES_PT_CONTINUUM;
+  if (st_crossed(&trk)) st = ES_PT_CONTINUUM;
   return st;
 }
 

@@ -32,4 +32,4 @@ def test_port_vs_truth(name):
         # RK4 on the reference's grid vs adaptive DOP853: 4th-order discretisation error
         tol = 3e-8 * max(1.0, (1000.0 / eq.n_nodes) ** 4)
         assert abs(D[i] - d) <= tol * scale, (name, kk[i], ww[i], D[i], d)
-    assert n_ok >= 4 or n_cont >= 6, name
+    assert n_ok >= 4, (name, n_ok, n_cont)
