@@ -28,15 +28,15 @@ sys.path.insert(0, ROOT)
 
 NK = NW = 4096
 W_LO, W_HI = 0.8944271909999159, 5.0          # (cT_i0, vA_e) of the coronal cylinder
-N_BISECT = 26                                 # bracket width <= 2^-26 * k dW  ->  |d omega/omega| < 1e-10
-REFINE_ROUNDS = 9                             # 9-section rounds: 9^9 >= 2^26 (8 evaluations per round and bracket)
+N_BISECT = 24                                 # bracket width <= 2^-24 * k dW ~ 6e-11 omega -> midpoint error < 1e-10 omega
+REFINE_ROUNDS = 8                             # 9-section rounds: 9^8 >= 2^24 (8 evaluations per round and bracket)
 TOL_PERCENT = 1e-3
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 # algorithmic traffic per det-eval of the grid kernel: 8 B D + 1 B status written, inputs amortised
 BYTES_PER_EVAL = 8.0 + 1.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-FLOPS_PER_STEP = 2 * 10 + 7 + 28            # 2 coefficient sets (10 each) + shared reciprocal (1 div + 6 mul) + one adjoint RK4 column
+FLOPS_PER_STEP = 2 * 10 + 6 + 32            # 2 coefficient sets (10 each) + shared reciprocal (1 div + 5 mul) + one adjoint RK4 step (32)
 
 
 def workload_equilibrium():

@@ -50,6 +50,11 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
         inr[p] = iw < nw;
         w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
       }
+      // exterior closed form first: here only w[] is live, so the ~100 VGPRs of the Bessel code overlap with nothing
+      // and only its three results per point are carried through the march (no call frame, no scratch)
+      ExteriorLite X[PTS];
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) X[p] = exterior_lite(P, k, w[p]);
       // adjoint march: chunks from the far end of the interior back to the boundary
       const int nchunks = (nsteps + CH - 1) / CH;
       for (int c = nchunks - 1; c >= 0; --c) {
@@ -98,10 +103,9 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
       for (int p = 0; p < PTS; ++p) {
         if (!inr[p]) continue;
         const int iw = w0 + p * T + (int)threadIdx.x;
-        const Exterior X = exterior_any(P, k, w[p]);
-        const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X, zp[p], zq[p], ef);
+        const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X[p], zp[p], zq[p], ef);
         double D, rel; uint8_t st;
-        finish_point(P, M, X, trk[p].crossed(), D, rel, st);
+        finish_point(P, M, X[p], trk[p].crossed(), D, rel, st);
         const size_t o = (size_t)row * nw + iw;
         Dout[o] = D;
         stout[o] = st;
@@ -231,15 +235,16 @@ int check_problem(es_context* ctx, const es_problem* prob) {
 }
 
 // Launch geometry of the grid kernel: workgroup = one k-row, threads cover omega, PTS points per lane.
-//   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)      -- default for wide rows
-//   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD)
-//   variant 2: PTS = 1, up to 1024 threads
+//   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)
+//   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD, no scratch)  -- default for rows >= 2048 wide
+//   variant 2: PTS = 1, up to 1024 threads                                         -- narrow rows (worker batches)
+// Variants 0 and 1 run at the same speed (the kernel is VALU-issue bound, measured 35.9 ms both at 4096^2).
 // ES_GRID_VARIANT in the environment overrides the default (tuning aid).
 template <int FAM>
 int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
                 int w_mode, double* d_D, double* d_rel, uint8_t* d_status) {
   const int grid = nk < 65535 ? nk : 65535;
-  int variant = (nw >= 1024) ? 0 : 2;
+  int variant = (nw >= 2048) ? 1 : ((nw >= 1024) ? 0 : 2);
   if (const char* ev = getenv("ES_GRID_VARIANT")) variant = atoi(ev);
   auto roundT = [](int pts_needed, int maxT) {
     int T = (pts_needed + 63) / 64 * 64;

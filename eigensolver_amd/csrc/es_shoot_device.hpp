@@ -367,16 +367,16 @@ __device__ __forceinline__ Exterior exterior_slab(const ShootDev& P, double k, d
 
 // ---- boundary algebra ------------------------------------------------------------------------------------------
 // Inputs: the row r = (r1, r2) of the transfer matrix selected by the far-end condition (r . (u_b, v_b) = target),
-// the node entries of the first node and the exterior.  Output: mismatch d = outer - inner and the two terms.
+// the node entries of the first node and the exterior (outer = cst * dyb, yb, Oe).  Output: mismatch d = outer - inner.
 struct Mismatch { double d, outer, inner; };
 
-template <int FAM>
-__device__ __forceinline__ Mismatch boundary_algebra(const ShootDev& P, const KScal& s, double w, const Exterior& X,
+template <int FAM, class Ext>
+__device__ __forceinline__ Mismatch boundary_algebra(const ShootDev& P, const KScal& s, double w, const Ext& X,
                                                      double r1, double r2, const double* e_first) {
   Mismatch M;
   if (FAM == FAM_CYL0 || FAM == FAM_CYLT) {
     const double Pb = X.yb;
-    const double xi_e = X.cst * X.dyb;                                  // left_xi_solution[-1], CF:775
+    const double xi_e = X.outer;                                        // left_xi_solution[-1], CF:775
     double Xb;
     if (P.axis_bc == ES_AXIS_KINK) {
       Xb = (P.bc_const * xi_e - r1 * Pb) / r2;                          // P(r_ax) = B_phi(-1)^2 xi_e, CF:795
@@ -388,7 +388,7 @@ __device__ __forceinline__ Mismatch boundary_algebra(const ShootDev& P, const KS
     const double xi_i = Xb / P.xb;                                      // inside_xi_solution[0], CF:798
     M.outer = xi_e; M.inner = xi_i; M.d = xi_e - xi_i;
   } else {
-    const double P_left = X.cst * X.dyb;                                // left_P_solution[-1], SF-U:559
+    const double P_left = X.outer;                                      // left_P_solution[-1], SF-U:559
     if (FAM == FAM_SLABD) {
       const double Vb = X.yb;                                           // SD-P:473
       const double sv = (P.slab_sign - r1) * Vb / r2;                   // v(-1) = F Vx'(-1)

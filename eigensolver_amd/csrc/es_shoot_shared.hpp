@@ -25,13 +25,26 @@ __device__ __forceinline__ double pick_w(const double* __restrict__ wv, int w_mo
   return wv[iw];
 }
 
-// Deliberately NOT inlined: the Bessel series / continued fraction need ~100 VGPRs of their own; as a real call
-// they stay out of the register allocation of the RK4 loop (the call sits after the loop, once per point).
-static __device__ __noinline__ Exterior exterior_any(const ShootDev& P, double k, double w) {
-  return (P.family == FAM_CYL0 || P.family == FAM_CYLT) ? exterior_cylinder(P, k, w) : exterior_slab(P, k, w);
+// What the boundary algebra needs from the exterior: outer = cst * dyb (xi_e resp. P_left), the normalised boundary
+// value yb (+-1), the Doppler-shifted exterior frequency (flow slab) and the status.
+struct ExteriorLite {
+  double outer, yb, Oe;
+  int status;
+};
+
+// Evaluated BEFORE the RK4 march (few live registers), inlined: the Bessel series / continued fraction need ~100
+// VGPRs of their own, which then overlap with nothing; only the three results are carried through the loop.
+__device__ __forceinline__ ExteriorLite exterior_lite(const ShootDev& P, double k, double w) {
+  const Exterior X = (P.family == FAM_CYL0 || P.family == FAM_CYLT) ? exterior_cylinder(P, k, w) : exterior_slab(P, k, w);
+  ExteriorLite L;
+  L.outer = X.cst * X.dyb;
+  L.yb = X.yb;
+  L.Oe = X.Oe;
+  L.status = X.status;
+  return L;
 }
 
-__device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& M, const Exterior& X, bool crossed,
+__device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& M, const ExteriorLite& X, bool crossed,
                                              double& D, double& rel, uint8_t& st) {
   st = (uint8_t)X.status;
   D = M.d;
@@ -54,6 +67,7 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
   SignTrack trk;
   double b[NB], e[NE], e2[NE];
+  const ExteriorLite X = exterior_lite(P, k, w);
   // adjoint march from the last node back to the boundary (same arithmetic as the grid kernel)
   load_base<FAM>(P, 2 * nsteps, b);
   make_entry<FAM>(b, s, e);
@@ -71,7 +85,6 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
     rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
     B0 = B1;
   }
-  const Exterior X = exterior_any(P, k, w);
   const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
   finish_point(P, M, X, trk.crossed(), D, rel, st);
 }
