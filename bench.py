@@ -45,6 +45,21 @@ def workload_equilibrium():
     return q.CylinderFlow(U_i0=0.7, width=0.9)
 
 
+def measured_traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command, profiles/README.md); None if not yet profiled."""
+    path = os.path.join(ROOT, "profiles", "bench_pmc_hbm_latest.json")
+    try:
+        d = json.load(open(path))
+        f = [v["mean_KB_per_dispatch"] for k, v in d["FETCH_SIZE"].items() if "shoot_grid_kernel" in k][0]
+        w = [v["mean_KB_per_dispatch"] for k, v in d["WRITE_SIZE"].items() if "shoot_grid_kernel" in k][0]
+        # gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads (x2 correction of the guide);
+        # the reads of this kernel are 8-B scalar/LDS-staging loads of a 56 KB table, left uncorrected
+        return (f + w) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(eq, m, k_np, W_np, target_seconds=12.0):
     """The oracle's C port (same algorithm, plain C + OpenMP) on a bounded sample of the same workload."""
     from oracle.port import PortProblem
@@ -154,7 +169,8 @@ def main():
                        "brackets_per_step": brackets_total, "roots_per_step": roots_total,
                        "parallelism": f"m-tiled x{world}, one RCCL all-gather of the root table" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "shoot_grid_kernel<FAM_CYL0>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic_per_launch(), "algorithmic_bytes_per_launch": grid_evals * BYTES_PER_EVAL,
                          "avg_launch_ms": grid_ms,
                          "note": "fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
             "valu_fp64": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
