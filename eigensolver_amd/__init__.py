@@ -5,3 +5,4 @@ from . import equilibrium  # noqa: F401
 from .shooting import ShootProblem  # noqa: F401
 from .solvers import (CylinderNonUniformDensity, CylinderNonUniformFlow, CylinderRotationalFlow,  # noqa: F401
                       SlabNonUniformDensity, SlabNonUniformFlow, SlabUniformFlow)
+from .cyl_uniform import CylinderUniform  # noqa: F401

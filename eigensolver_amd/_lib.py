@@ -146,3 +146,19 @@ def _sig(lib):  # noqa: F811
     _orig_sig(lib)
     _sig_shoot(lib)
     return lib
+
+
+class CylUniformParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("c_i", "vA_i", "rho_i", "U_i", "rho_e", "vA_e", "c_e", "cT_e",
+                                           "r_boundary", "r_axis", "L_factor", "ic_value", "ic_slope")] + \
+               [("m", C.c_int32), ("m_ext", C.c_int32), ("axis_bc", C.c_int32), ("reserved", C.c_int32)]
+
+
+_orig_sig2 = _sig
+
+
+def _sig(lib):  # noqa: F811
+    _orig_sig2(lib)
+    vp, i = C.c_void_p, C.c_int
+    lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]
+    return lib

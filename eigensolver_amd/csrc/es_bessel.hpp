@@ -112,4 +112,56 @@ ES_HD void ie_pair(int n, double x, double& in_, double& inp1) {
   inp1 = ex * pre * (hx / ((double)n + 1.0)) * sum_b;
 }
 
+// J_n, J_{n+1}, Y_n, Y_{n+1} for integer n >= 0, x > 0 (body modes of the uniform cylinder: m_i < 0).
+// One Miller backward recurrence J_{k-1} = (2k/x) J_k - J_{k+1} from an even start index M > x gives all J_k up to a
+// common factor, fixed by 1 = J_0 + 2 sum_{k>=1} J_{2k}; Y_0 and Y_1 follow from the Neumann series
+//   (pi/2) Y_0 = (ln(x/2)+gamma) J_0 + 2 sum_{k>=1} (-1)^{k+1} J_{2k}/k                       (A&S 9.1.88)
+//   (pi/2) Y_1 = -J_0/x + (ln(x/2)+gamma-1) J_1 - sum_{k>=1} (-1)^k (2k+1) J_{2k+1}/(k(k+1))  (A&S 9.1.89, n = 1)
+// accumulated during the same recurrence, and Y_n by the (stable) upward recurrence.
+ES_HD void jy_pair(int n, double x, double& jn, double& jn1, double& yn, double& yn1) {
+  int M = (int)(1.15 * x) + 36 + n;
+  M += (M & 1);                                   // even
+  const double tox = 2.0 / x;
+  double jp = 0.0, jc = 1e-280;                   // J_{M+1}, J_M (arbitrary scale)
+  double norm = 0.0, sy0 = 0.0, sy1 = 0.0;        // sum J_{2k}; sum (-1)^{k+1} J_{2k}/k; sum (-1)^k (2k+1) J_{2k+1}/(k(k+1))
+  double rn = 0.0, rn1 = 0.0;
+  for (int k = M; k >= 1; --k) {                  // jc = J_k on entry
+    if (k == n) rn = jc;
+    if (k == n + 1) rn1 = jc;
+    const int h = k >> 1;
+    const double sgn = (h & 1) ? -1.0 : 1.0;      // (-1)^h
+    if ((k & 1) == 0) {                           // k = 2h, h >= 1
+      norm += jc;
+      sy0 -= sgn * jc / (double)h;                // (-1)^{h+1} J_{2h}/h
+    } else if (k >= 3) {                          // k = 2h+1, h >= 1
+      sy1 += sgn * (double)k * jc / ((double)h * (double)(h + 1));
+    }
+    const double jm = (double)k * tox * jc - jp;  // J_{k-1}
+    jp = jc;
+    jc = jm;
+    if (fabs(jc) > 1e250) {                       // rescale everything accumulated so far
+      const double sc = 1e-250;
+      jc *= sc; jp *= sc; norm *= sc; sy0 *= sc; sy1 *= sc; rn *= sc; rn1 *= sc;
+    }
+  }
+  // now jc = J_0, jp = J_1 (unnormalised)
+  if (n == 0) rn = jc;
+  if (n + 1 == 1) rn1 = jp;
+  const double inv = 1.0 / (jc + 2.0 * norm);
+  const double j0 = jc * inv, j1 = jp * inv;
+  const double lg = log(0.5 * x) + kEulerGamma;
+  const double y0 = (2.0 / kPi) * (lg * j0 + 2.0 * sy0 * inv);
+  const double y1 = (2.0 / kPi) * (-j0 / x + (lg - 1.0) * j1 - sy1 * inv);
+  jn = rn * inv;
+  jn1 = rn1 * inv;
+  double a = y0, b = y1;                          // (Y_{j-1}, Y_j) -> (Y_j, Y_{j+1})
+  for (int j = 1; j <= n; ++j) {
+    const double c = (double)j * tox * b - a;
+    a = b;
+    b = c;
+  }
+  yn = a;
+  yn1 = b;
+}
+
 }  // namespace esb

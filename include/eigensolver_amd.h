@@ -195,6 +195,27 @@ int es_worker_run(es_context* ctx, const es_problem* prob, const es_worker_spec*
                   const double* d_k, int ntasks, const double* d_freq, int nfreq,
                   double* d_roots, int32_t* d_nroots, int max_roots, int32_t* d_nevals /* may be NULL */);
 
+/* ========================================================================================================
+ * (4) Uniform cylinder in closed form (the limit the reference uses as its benchmark case, profile width 1e5,
+ *     e.g. Cylinder_method_flow_testing.py:126): the interior ODE is then Bessel's equation, so the same
+ *     determinant follows from I_m/K_m (m_i > 0) or J_m/Y_m (m_i < 0, body modes) of sqrt(|m_i|) r with the
+ *     K_m/Y_m admixture fixed by the reference's axis condition at r_axis, matched to the exterior K_m/I_m
+ *     solution.  No ODE is integrated.  Same normalisation, status codes and rel as es_shoot_eval_grid.
+ * ====================================================================================================== */
+typedef struct es_cyl_uniform_params {
+  double c_i, vA_i, rho_i, U_i;          /* uniform interior: sound speed, Alfven speed, density, axial flow */
+  double rho_e, vA_e, c_e, cT_e;         /* exterior                                                        */
+  double r_boundary;                     /* -1 or +1 (sign convention of the reference file)                */
+  double r_axis;                         /* |r| of the inner end of the reference's ix grid (0.001 / 0.01)   */
+  double L_factor, ic_value, ic_slope;   /* far field of the exterior solve                                  */
+  int32_t m, m_ext, axis_bc;             /* ES_AXIS_KINK (P(r_ax) = 0) or ES_AXIS_SAUSAGE (P'(r_ax) = 0)      */
+  int32_t reserved;
+} es_cyl_uniform_params;
+
+int es_cyl_uniform_eval(es_context* ctx, const es_cyl_uniform_params* p, const double* d_k, int nk,
+                        const double* d_w, int nw, int w_mode,
+                        double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
+
 #ifdef __cplusplus
 }
 #endif

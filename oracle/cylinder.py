@@ -267,3 +267,62 @@ class CylinderProblem:
         if not np.isfinite(d):
             st = ST_NONFINITE
         return d, xi_e, xi_i, st
+
+
+def uniform_closed_form(eq, k, w, m, r_sign=-1.0, r_axis=1e-3, L_factor=3.0, ic=(1e-8, 1e-8), axis_bc="kink",
+                        U_i=0.0):
+    """ORACLE: the determinant of the UNIFORM cylinder (profile width -> infinity, the reference's benchmark case) in
+    closed form with scipy's Bessel functions: interior I_m/K_m (m_i > 0) or J_m/Y_m (m_i < 0) of sqrt(|m_i|) |r| with
+    the second-kind admixture fixed by the axis condition at r_axis, exterior as CylinderProblem.exterior.
+    Returns (d, xi_e, xi_i, status) in the normalisation of CylinderProblem.mismatch.
+    Follows SURVEY.md section 8a ("uniform, untwisted, static limit") and appendix A.4."""
+    prob = CylinderProblem(eq, m, r_sign=r_sign, r_axis=r_axis, L_factor=L_factor, ic=ic, axis_bc=axis_bc)
+    m_e, xi_c, Pb, dPb = prob.exterior(k, w)
+    if np.isfinite(m_e) and m_e < 0.0:
+        return float("nan"), float("nan"), float("nan"), ST_LEAKY
+    if not np.isfinite(Pb):
+        return float("nan"), float("nan"), float("nan"), ST_NONFINITE
+    c2, vA2, rho = eq.c_i0 ** 2, eq.vA_i0 ** 2, eq.rho_i0
+    S = c2 + vA2
+    cT2 = c2 * vA2 / S
+    k2 = k * k
+    Om = w - k * U_i
+    Om2 = Om * Om
+    with np.errstate(all="ignore"):
+        m_i = (k2 * vA2 - Om2) * (k2 * c2 - Om2) / (S * (k2 * cT2 - Om2))
+    n = float(m)
+    if m_i > 0:
+        kap = math.sqrt(m_i)
+        xa, xb = kap * r_axis, kap
+
+        def f1(x):   # e^-x I, e^-x I'
+            a, b = special.ive(n, x), special.ive(n + 1, x)
+            return a, b + (n / x) * a
+
+        def f2(x):   # e^x K, e^x K'
+            a, b = special.kve(n, x), special.kve(n + 1, x)
+            return a, -b + (n / x) * a
+        Ia, dIa = f1(xa); Ka, dKa = f2(xa); Ib, dIb = f1(xb); Kb, dKb = f2(xb)
+        E2 = math.exp(-2.0 * (xb - xa))
+        g = -(dIa / dKa) if axis_bc == "sausage" else -(Ia / Ka)
+        ld = kap * (dIb + E2 * g * dKb) / (Ib + E2 * g * Kb)
+    elif m_i < 0:
+        kap = math.sqrt(-m_i)
+        xa, xb = kap * r_axis, kap
+
+        def fj(x):
+            a, b = special.jv(n, x), special.jv(n + 1, x)
+            return a, -b + (n / x) * a
+
+        def fy(x):
+            a, b = special.yv(n, x), special.yv(n + 1, x)
+            return a, -b + (n / x) * a
+        Ja, dJa = fj(xa); Ya, dYa = fy(xa); Jb, dJb = fj(xb); Yb, dYb = fy(xb)
+        g = -(dJa / dYa) if axis_bc == "sausage" else -(Ja / Ya)
+        ld = kap * (dJb + g * dYb) / (Jb + g * Yb)
+    else:
+        return float("nan"), float("nan"), float("nan"), ST_NONFINITE
+    xi_e = xi_c * dPb
+    xi_i = r_sign * ld * Pb / (rho * (Om2 - k2 * vA2))
+    d = xi_e - xi_i
+    return d, xi_e, xi_i, (ST_OK if np.isfinite(d) else ST_NONFINITE)

@@ -5,4 +5,5 @@
 extern "C" {
 void hm_ke_pair(int n, double x, double* out) { esb::ke_pair(n, x, out[0], out[1]); }
 void hm_ie_pair(int n, double x, double* out) { esb::ie_pair(n, x, out[0], out[1]); }
+void hm_jy_pair(int n, double x, double* out) { esb::jy_pair(n, x, out[0], out[1], out[2], out[3]); }
 }
