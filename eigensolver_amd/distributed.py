@@ -45,6 +45,9 @@ def gather_root_tables(roots, m, world=None, group=None):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return rec
+    home = rec.device
+    if dist.get_backend(group) == "gloo" and rec.is_cuda:
+        rec = rec.cpu()                 # rehearsal mode: gloo ranks sharing one GPU exchange through host memory
     n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -54,4 +57,4 @@ def gather_root_tables(roots, m, world=None, group=None):
     padded[:rec.shape[0]] = rec
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(home)
