@@ -134,10 +134,56 @@ def _run(name):
     try:
         if name == "slab_analytic":
             return gen_slab_analytic()
+        if name == "equilibria":
+            return gen_equilibrium_fixture()
         return gen_case(name)
     except Exception as e:  # noqa
         import traceback
         return f"{name}: FAILED {type(e).__name__}: {e}\n{traceback.format_exc()}"
+
+
+# ----------------------------------------------------------------------------------------------------
+# a9 / a10 fixtures: the reference's `speeds` lists and lambdified equilibrium profiles at sample points
+def gen_equilibrium_fixture():
+    import ref_harness as H
+    out = {}
+    cfgs = {
+        "CD-C": [], "CD-C_w15": [("dr=0.95", "dr=1.5")], "CD-P": [], "CF": [],
+        "CF_flow": [("dr=1e5", "dr=1."), ("U_i0 = 0.*c_i0", "U_i0 = 0.6*c_i0")],
+        "CR-KF": [], "CR-KS": [], "CR-SF": [], "CR-SS": [],
+        "SD-P_w15": [("dx=1e5", "dx=1.5"), ("1e5)  # inside slab x values", "2001)  # inside slab x values")],
+        "SD-C": [("1e6)  # inside slab x values     #was 500", "2001)  # inside slab x values")],
+        "SF-G_flow": [("dx=1e5", "dx=1.5"), ("U_i0 = 0.9*vA_i", "U_i0 = 0.35*vA_i")],
+    }
+    for tag, repl in cfgs.items():
+        key = tag.split("_")[0]
+        ns = H.load_worker_module(key, repl)
+        rec = {"file": H.FILES[key], "replacements": repl}
+        if "speeds" in ns:
+            rec["speeds"] = [float(x) for x in ns["speeds"]]
+        for name in ("rho_e", "cT_e", "c_kink", "cT_i0", "R1"):
+            if name in ns:
+                v = ns[name]
+                rec[name] = float(v() if callable(v) else v)
+        cyl = key.startswith("C")
+        sign = -1.0 if key in ("CD-C", "CF") else 1.0
+        pts = (sign * np.array([1.0, 0.75, 0.5, 0.25, 0.1, 0.01])) if cyl else np.array([-1.0, -0.6, -0.2, 0.0, 0.3, 0.9])
+        rec["points"] = [float(x) for x in pts]
+        for fn in ("rho_i_np", "c_i_np", "vA_i_np", "cT_i_np", "v_iphi_np", "P_i_np", "B_i_np", "U_i_np", "dU_i_np",
+                   "ddU_i_np"):
+            if fn in ns:
+                with np.errstate(all="ignore"):
+                    v = np.broadcast_to(np.asarray(ns[fn](pts), dtype=float), pts.shape)
+                rec[fn] = [float(x) for x in v]
+        if "v_z" in ns and callable(ns["v_z"]):
+            import sympy as sym
+            rr = sym.symbols("r")
+            f = sym.lambdify(rr, ns["v_z"](rr), "numpy")
+            rec["v_z"] = [float(x) for x in np.broadcast_to(np.asarray(f(pts), dtype=float), pts.shape)]
+        out[tag] = rec
+    with open(os.path.join(GOLD, "equilibria.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    return "equilibria.json"
 
 
 if __name__ == "__main__":
@@ -146,10 +192,11 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=6)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    names = ["slab_analytic"] + list(CASES)
+    names = ["slab_analytic", "equilibria"] + list(CASES)
     if a.only:
         names = [n for n in names if n in a.only.split(",")]
     import multiprocessing as mp
     with mp.Pool(a.jobs) as pool:
         for msg in pool.imap_unordered(_run, names):
             print(msg, flush=True)
+
