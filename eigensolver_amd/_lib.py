@@ -161,4 +161,5 @@ def _sig(lib):  # noqa: F811
     _orig_sig2(lib)
     vp, i = C.c_void_p, C.c_int
     lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]
+    lib.es_shoot_eigenfunction.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
     return lib

@@ -114,6 +114,25 @@ class ShootProblem:
         _lib.check(self.ctx.handle, rc)
         return (D, st, rel) if want_rel else (D, st)
 
+    def eigenfunction(self, k, w, n_ext=500):
+        """Two-region solution at the (k, omega) pairs: dict of CUDA tensors x_int [N], value_int/flux_int [n, N],
+        x_ext/value_ext/flux_ext [n, n_ext] (cylinders: P and xi_r; slabs: Vx and P_T), exterior boundary value +-1."""
+        import torch
+        dk, dw = self._dev(k).reshape(-1), self._dev(w).reshape(-1)
+        n, N = dk.numel(), int(self.desc.n_nodes)
+        dev = dk.device
+        vi = torch.empty((n, N), dtype=torch.float64, device=dev)
+        fi = torch.empty((n, N), dtype=torch.float64, device=dev)
+        xe = torch.empty((n, n_ext), dtype=torch.float64, device=dev)
+        ve = torch.empty((n, n_ext), dtype=torch.float64, device=dev)
+        fe = torch.empty((n, n_ext), dtype=torch.float64, device=dev)
+        rc = self.ctx.lib.es_shoot_eigenfunction(self.ctx.handle, self.handle, _lib.ptr(dk), _lib.ptr(dw), n,
+                                                 _lib.ptr(vi), _lib.ptr(fi), int(n_ext), _lib.ptr(xe), _lib.ptr(ve),
+                                                 _lib.ptr(fe))
+        _lib.check(self.ctx.handle, rc)
+        x_int = torch.linspace(self.desc.x_boundary, self.desc.x_end, N, dtype=torch.float64, device=dev)
+        return dict(x_int=x_int, value_int=vi, flux_int=fi, x_ext=xe, value_ext=ve, flux_ext=fe)
+
     def alloc_root_table(self, capacity):
         import torch
         dev = f"cuda:{self.ctx.device}"

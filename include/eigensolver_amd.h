@@ -216,6 +216,21 @@ int es_cyl_uniform_eval(es_context* ctx, const es_cyl_uniform_params* p, const d
                         const double* d_w, int nw, int w_mode,
                         double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
 
+/* ========================================================================================================
+ * (5) Eigenfunctions at given (k, omega) -- the two-region solve the reference's analysis scripts repeat at a
+ *     chosen root to plot P_T(r) and xi_r(r) (Cylinder/Non-uniform flow/Coronal/Eigenfunctions/
+ *     analysis_cylinder_flow_coronal.py:813-924): interior on the problem's node grid (linspace(x_boundary,
+ *     x_end, N)), exterior on linspace(-/+ L*2pi/k, -/+1, n_ext) in closed form.
+ *     Cylinders: value = P, flux = xi_r (= xi_e_const P' outside, (C1 P + D P')/C3 inside); slabs: value = Vx,
+ *     flux = total pressure P_T.  Both regions are scaled so that the exterior value at the boundary is +-1 (sign
+ *     of the reference's amplitude); the reference's plot normalisation (division by max|exterior|) is a host-side
+ *     step on these arrays.  Layout: [i * N + j] / [i * n_ext + j] for pair i, node j (node 0 = boundary for the
+ *     interior arrays; exterior arrays run from the far field to the boundary).
+ * ====================================================================================================== */
+int es_shoot_eigenfunction(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w, int n,
+                           double* d_int_value, double* d_int_flux,            /* n x N      */
+                           int n_ext, double* d_ext_x, double* d_ext_value, double* d_ext_flux /* n x n_ext */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,6 +269,57 @@ class CylinderProblem:
         return d, xi_e, xi_i, st
 
 
+def eigenfunction(prob, k, w, n_nodes, n_ext=500, rtol=1e-12):
+    """ORACLE: the two-region solution at (k, omega) the reference's analysis scripts plot
+    (Cylinder/Non-uniform flow/Coronal/Eigenfunctions/analysis_cylinder_flow_coronal.py:813-924): interior P and
+    xi_r on linspace(r_b, r_ax, n_nodes) by DOP853 from the boundary state fixed by the axis condition, exterior on
+    linspace(-/+ L 2pi/k, -/+1, n_ext) in closed form; scaled so that |P_e(r_b)| = 1 (sign of the reference's amplitude).
+    Returns dict(r_int, P_int, xi_int, r_ext, P_ext, xi_ext)."""
+    eq = prob.eq
+    m_e, xi_c, Pb, dPb = prob.exterior(k, w)
+    xi_e = xi_c * dPb
+    rb, ra = prob.r_sign, prob.r_sign * prob.r_axis
+    T = prob.transfer(k, w, rtol)
+    if prob.axis_bc == "kink":
+        target = float(eq.B_phi(np.array([rb]))[0]) ** 2 * xi_e
+        Xb = (target - T[0, 0] * Pb) / T[0, 1]
+    elif prob.axis_bc == "rotation_kink":
+        one = np.array([1.0])
+        cst = float(eq.B_phi(one)[0]) ** 2 - float(eq.rho(one)[0]) * float(eq.v_phi(one)[0]) ** 2
+        Xb = (-cst * xi_e - T[0, 0] * Pb) / T[0, 1]
+    else:
+        D, C1, C2, C3, _, _ = prob.coefficients(np.array([ra]), k, w)
+        al, be = C3[0] / (ra * D[0]), -C1[0] / D[0]
+        Xb = -(al * T[1, 0] + be * T[0, 0]) * Pb / (al * T[1, 1] + be * T[0, 1])
+    r_int = np.linspace(rb, ra, n_nodes)
+    sol = solve_ivp(prob._rhs, (rb, ra), np.array([Pb, Xb]), method="DOP853", rtol=rtol, atol=1e-300,
+                    t_eval=r_int, args=(k, w))
+    P_int, X_int = sol.y[0], sol.y[1]
+    # exterior
+    mu = math.sqrt(m_e)
+    sgn = prob.r_sign
+    R = prob.L_factor * 2.0 * math.pi / k
+    r_ext = np.linspace(sgn * R, sgn * 1.0, n_ext)
+    n = prob.m_ext
+    xR, xb = mu * R, mu
+    x = mu * np.abs(r_ext)
+    ic0, ic1 = prob.ic
+    g = ic1 / (sgn * mu)
+    KR, KR1 = special.kve(n, xR), special.kve(n + 1, xR)
+    IR, IR1 = special.ive(n, xR), special.ive(n + 1, xR)
+    dKR, dIR = -KR1 + (n / xR) * KR, IR1 + (n / xR) * IR
+    a_s, b_s = -(ic0 * dKR - g * KR), -(g * IR - ic0 * dIR)
+    Kx, Kx1, Ix, Ix1 = special.kve(n, x), special.kve(n + 1, x), special.ive(n, x), special.ive(n + 1, x)
+    dKx, dIx = -Kx1 + (n / x) * Kx, Ix1 + (n / x) * Ix
+    Kb, Ib = special.kve(n, xb), special.ive(n, xb)
+    den = abs(b_s * Kb + math.exp(-2 * (xR - xb)) * a_s * Ib)
+    dec = np.exp(-(x - xb))
+    E2x = np.exp(-2 * (xR - x))
+    P_ext = dec * (b_s * Kx + E2x * a_s * Ix) / den
+    dP_ext = sgn * mu * dec * (b_s * dKx + E2x * a_s * dIx) / den
+    return dict(r_int=r_int, P_int=P_int, xi_int=X_int / r_int, r_ext=r_ext, P_ext=P_ext, xi_ext=xi_c * dP_ext)
+
+
 def uniform_closed_form(eq, k, w, m, r_sign=-1.0, r_axis=1e-3, L_factor=3.0, ic=(1e-8, 1e-8), axis_bc="kink",
                         U_i=0.0):
     """ORACLE: the determinant of the UNIFORM cylinder (profile width -> infinity, the reference's benchmark case) in

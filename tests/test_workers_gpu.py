@@ -142,3 +142,42 @@ def test_driver_block_layout(es_ctx):
         assert w.shape == k.shape and w.dtype == np.float64
     assert len(out["kink"][0]) > 0
     s.close()
+
+
+ROOTSET_SOLVERS = {
+    "CF_flow": ("CF_flow", "CF"), "CF_uniform": ("CF_uniform", "CF"), "CDC_w095": ("CDC_w095", "CD-C"),
+    "SFG_flow": ("SFG_flow", "SF-G"), "CRKS": ("CRKS", "CR-KS"),
+}
+
+
+@pytest.mark.parametrize("name", list(ROOTSET_SOLVERS))
+def test_driver_sweep_vs_reference_root_sets(es_ctx, name):
+    """Driver-style sweeps (k x band x mode, 30-40 point bands) of the reference workers executed in the build
+    container (tests/golden/roots_*.json): all calls of a sweep go to the GPU as ONE batch; the root lists must be
+    the reference's, value for value (|d omega/omega| < 1e-10), for the large majority of calls -- the remainder are
+    decisions inside the reference's own LSODA/fsolve noise (its acceptance measure within ~1e-3 of the tolerance,
+    or fsolve failures)."""
+    path = os.path.join(G, f"roots_{name}.json")
+    if not os.path.exists(path):
+        pytest.skip("root set not generated")
+    solver, key = _solvers(es_ctx)[ROOTSET_SOLVERS[name][0]]
+    rs = json.load(open(path))
+    by_mode = {}
+    for c in rs["calls"]:
+        by_mode.setdefault((c["fn"], c["n"]), []).append(c)
+    n_calls = n_same = n_roots_ref = n_roots_match = 0
+    for (mode, n), calls in by_mode.items():
+        ks = [c["k"] for c in calls]
+        fr = np.stack([np.linspace(c["band"][0] * c["k"], c["band"][1] * c["k"], n) for c in calls])
+        got = solver.run_batch(mode, ks, fr)
+        for c, mine in zip(calls, got):
+            ref = c["roots_w"]
+            n_calls += 1
+            n_roots_ref += len(ref)
+            same = len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref))
+            n_same += same
+            n_roots_match += sum(1 for b in ref if any(abs(a - b) <= 1e-10 * abs(b) for a in mine))
+    assert n_calls >= 10
+    assert n_same >= 0.75 * n_calls, (name, n_same, n_calls)
+    assert n_roots_ref == 0 or n_roots_match >= 0.75 * n_roots_ref, (name, n_roots_match, n_roots_ref)
+    solver.close()

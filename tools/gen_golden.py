@@ -136,6 +136,8 @@ def _run(name):
             return gen_slab_analytic()
         if name == "equilibria":
             return gen_equilibrium_fixture()
+        if name.startswith("roots:"):
+            return gen_rootset(name[6:])
         return gen_case(name)
     except Exception as e:  # noqa
         import traceback
@@ -186,13 +188,47 @@ def gen_equilibrium_fixture():
     return "equilibria.json"
 
 
+# ----------------------------------------------------------------------------------------------------
+# Larger root sets: whole driver-style sweeps (k x band x mode) of the reference workers, roots only.
+ROOTSETS = {
+    "CF_flow": ("CF", [("dr=1e5", "dr=1."), ("U_i0 = 0.*c_i0", "U_i0 = 0.6*c_i0")],
+                [0.4, 0.9, 1.4, 1.9, 2.4, 2.9, 3.4, 3.9], [(2.7, 4.95)], 40, ("kink", "sausage")),
+    "CF_uniform": ("CF", [], [0.3, 0.8, 1.3, 1.8, 2.3, 2.8, 3.3, 3.8], [(2.05, 4.95), (0.9, 0.99)], 40, ("kink", "sausage")),
+    "CDC_w095": ("CD-C", [], [0.6, 1.2, 1.8, 2.4, 3.0, 3.6, 4.2], [(2.05, 4.95)], 40, ("kink", "sausage")),
+    "SFG_flow": ("SF-G", [("dx=1e5", "dx=1.5"), ("U_i0 = 0.9*vA_i", "U_i0 = 0.35*vA_i")],
+                 [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.4, 2.45)], 40, ("kink", "sausage")),
+    "CRKS": ("CR-KS", [], [0.6, 1.0, 1.5, 2.0, 3.0], [(0.7, 0.99), (1.21, 1.44)], 30, ("kink",)),
+}
+
+
+def gen_rootset(name):
+    import ref_harness as H
+    key, repl, ks, bands, n, modes = ROOTSETS[name]
+    t0 = time.time()
+    ns = H.load_worker_module(key, repl)
+    init = H.snapshot_initial(ns)
+    out = {"case": name, "file": H.FILES[key], "replacements": repl, "calls": []}
+    for k in ks:
+        for lo, hi in bands:
+            freq = np.linspace(lo * k, hi * k, n)
+            for fn in modes:
+                rw, rk, tr = H.run_worker(ns, init, fn, float(k), freq)
+                iers = [e[3] for e in tr if e[0] == "fsolve"]
+                out["calls"].append({"fn": fn, "k": float(k), "band": [lo, hi], "n": n, "roots_w": rw,
+                                     "n_evals": len(H.evaluations(tr)), "n_fsolve_fail": int(sum(1 for i in iers if i != 1))})
+    out["seconds"] = round(time.time() - t0, 1)
+    with open(os.path.join(GOLD, f"roots_{name}.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return f"roots_{name}.json ({out['seconds']} s, {sum(len(c['roots_w']) for c in out['calls'])} roots)"
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--jobs", type=int, default=6)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    names = ["slab_analytic", "equilibria"] + list(CASES)
+    names = ["slab_analytic", "equilibria"] + list(CASES) + ["roots:" + n for n in ROOTSETS]
     if a.only:
         names = [n for n in names if n in a.only.split(",")]
     import multiprocessing as mp

@@ -29,3 +29,24 @@ for name, (solver, key) in _solvers(ctx).items():
     print(f"{name:12s} calls {calls:2d}  identical root lists {same:2d}  roots {roots:3d}  max|dw/w| {worst:.1e}")
     tot[0] += calls; tot[1] += same; tot[2] += roots
 print("total", tot)
+
+# larger driver-style sweeps
+from tests.test_workers_gpu import ROOTSET_SOLVERS  # noqa: E402
+for name, (skey, key) in ROOTSET_SOLVERS.items():
+    path = os.path.join(G, f"roots_{name}.json")
+    if not os.path.exists(path):
+        continue
+    solver, _ = _solvers(ctx)[skey]
+    rs = json.load(open(path))
+    calls = same = rref = rmatch = fails = 0
+    for c in rs["calls"]:
+        fr = np.linspace(c["band"][0] * c["k"], c["band"][1] * c["k"], c["n"])[None, :]
+        mine = solver.run_batch(c["fn"], [c["k"]], fr)[0]
+        ref = c["roots_w"]
+        calls += 1
+        fails += c["n_fsolve_fail"] > 0
+        rref += len(ref)
+        same += len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref))
+        rmatch += sum(1 for b in ref if any(abs(a - b) <= 1e-10 * abs(b) for a in mine))
+    print(f"sweep {name:12s} calls {calls:3d} identical lists {same:3d}  reference roots {rref:3d} reproduced {rmatch:3d}"
+          f"  (calls with fsolve failures in the reference: {fails})")
