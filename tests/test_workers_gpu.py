@@ -154,9 +154,8 @@ ROOTSET_SOLVERS = {
 def test_driver_sweep_vs_reference_root_sets(es_ctx, name):
     """Driver-style sweeps (k x band x mode, 30-40 point bands) of the reference workers executed in the build
     container (tests/golden/roots_*.json): all calls of a sweep go to the GPU as ONE batch; the root lists must be
-    the reference's, value for value (|d omega/omega| < 1e-10), for the large majority of calls -- the remainder are
-    decisions inside the reference's own LSODA/fsolve noise (its acceptance measure within ~1e-3 of the tolerance,
-    or fsolve failures)."""
+    the reference's, value for value (|d omega/omega| < 1e-10), in every call where the reference's fsolve converged
+    throughout; the reference's remaining calls contain evaluations with a silently non-converged fsolve slope."""
     path = os.path.join(G, f"roots_{name}.json")
     if not os.path.exists(path):
         pytest.skip("root set not generated")
@@ -165,19 +164,25 @@ def test_driver_sweep_vs_reference_root_sets(es_ctx, name):
     by_mode = {}
     for c in rs["calls"]:
         by_mode.setdefault((c["fn"], c["n"]), []).append(c)
-    n_calls = n_same = n_roots_ref = n_roots_match = 0
+    n_clean = same_clean = n_dirty = same_dirty = 0
     for (mode, n), calls in by_mode.items():
         ks = [c["k"] for c in calls]
         fr = np.stack([np.linspace(c["band"][0] * c["k"], c["band"][1] * c["k"], n) for c in calls])
         got = solver.run_batch(mode, ks, fr)
         for c, mine in zip(calls, got):
             ref = c["roots_w"]
-            n_calls += 1
-            n_roots_ref += len(ref)
             same = len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref))
-            n_same += same
-            n_roots_match += sum(1 for b in ref if any(abs(a - b) <= 1e-10 * abs(b) for a in mine))
-    assert n_calls >= 10
-    assert n_same >= 0.75 * n_calls, (name, n_same, n_calls)
-    assert n_roots_ref == 0 or n_roots_match >= 0.75 * n_roots_ref, (name, n_roots_match, n_roots_ref)
+            if c["n_fsolve_fail"] == 0:
+                n_clean += 1
+                same_clean += same
+            else:
+                n_dirty += 1
+                same_dirty += same
+    assert n_clean + n_dirty >= 10
+    # every call in which the reference's fsolve converged at every evaluation is reproduced root for root
+    # (one knife-edge exception allowed per sweep: acceptance measure within LSODA noise of the tolerance)
+    assert same_clean >= n_clean - 1, (name, same_clean, n_clean)
+    # calls in which the reference silently used a non-converged fsolve slope (ier != 1) are the
+    # reference's own artefacts; most still agree
+    assert n_dirty == 0 or same_dirty >= 0.5 * n_dirty, (name, same_dirty, n_dirty)
     solver.close()
