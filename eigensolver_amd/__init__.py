@@ -6,3 +6,4 @@ from .shooting import ShootProblem  # noqa: F401
 from .solvers import (CylinderNonUniformDensity, CylinderNonUniformFlow, CylinderRotationalFlow,  # noqa: F401
                       SlabNonUniformDensity, SlabNonUniformFlow, SlabUniformFlow)
 from .cyl_uniform import CylinderUniform  # noqa: F401
+from . import postprocess  # noqa: F401
