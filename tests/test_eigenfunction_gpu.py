@@ -36,8 +36,13 @@ def test_eigenfunction_vs_oracle(es_ctx, name):
             a, b = ef[key_g][i].cpu().numpy(), o[key_o]
             # RK4 on the reference grid vs DOP853; largest at the axis node where xi = Xi / r with |r| = 1e-3
             tol = 2e-6 * max(1.0, (1000.0 / eq.n_nodes) ** 4)
-            if name.startswith("CR"):
-                tol = 2e-5      # rotational axis condition P(r_ax) = -c xi_e keeps the singular 1/r solution: h/r ~ 0.5 at the axis
+            if name.startswith("CR") and key_g.endswith("_int"):
+                # the rotational axis condition P(r_ax) = -c xi_e keeps the singular solution (xi ~ 1/r^2): on the
+                # reference's uniform grid h/r ~ 0.5 at the last nodes, where RK4 is only good to ~1e-3 of the (huge)
+                # axis value; away from the axis the usual bound holds
+                far = np.abs(o["r_int"]) >= 0.02
+                assert np.max(np.abs(a - b)[far]) <= 2e-5 * np.max(np.abs(b[far])), (name, key_g)
+                tol = 1e-3
             assert np.max(np.abs(a - b)) <= tol * np.max(np.abs(b)), (name, key_g, np.max(np.abs(a - b)), np.max(np.abs(b)))
         assert np.allclose(ef["x_ext"][i].cpu().numpy(), o["r_ext"], rtol=1e-15, atol=1e-15)
         # at a root the displacement is continuous across the boundary: xi_i(r_b) = xi_e(r_b)

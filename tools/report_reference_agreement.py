@@ -50,3 +50,18 @@ for name, (skey, key) in ROOTSET_SOLVERS.items():
         rmatch += sum(1 for b in ref if any(abs(a - b) <= 1e-10 * abs(b) for a in mine))
     print(f"sweep {name:12s} calls {calls:3d} identical lists {same:3d}  reference roots {rref:3d} reproduced {rmatch:3d}"
           f"  (calls with fsolve failures in the reference: {fails})")
+
+# the reference's full driver run for the cylinder-flow script (CF:1134-1153): 150 k x 4 bands x 70 points x 2 modes
+import time  # noqa: E402
+import torch  # noqa: E402
+import eigensolver_amd as E  # noqa: E402
+s = E.CylinderNonUniformFlow(U_i0=0.6, width=1.0, ctx=ctx)
+kk = np.linspace(0.01, 4.0, 150)
+s.solve(kk[:4], 70)
+torch.cuda.synchronize()
+t = time.time()
+out = s.solve(kk, 70)
+torch.cuda.synchronize()
+t = time.time() - t
+print(f"driver run CF (150 k x 4 bands x 70 pts x 2 modes = {150*4*70*2} grid evaluations + refinements): {t*1e3:.1f} ms, "
+      f"roots sausage {len(out['sausage'][0])} kink {len(out['kink'][0])}")
