@@ -58,3 +58,32 @@ def gather_root_tables(roots, m, world=None, group=None):
     out = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(home)
+
+
+def gather_mode_results(local, group=None):
+    """All-gather per-mode (omega, k) arrays of a k-tiled driver run: local = {"sausage": (w, k), "kink": (w, k)}
+    (NumPy) -> the concatenation over ranks (rank-major) on every rank.  Same exchange pattern as
+    gather_root_tables: counts, then padded records."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    out = {}
+    for mode in sorted(local):
+        w, k = local[mode]
+        rec = torch.as_tensor(np.stack([np.asarray(w, dtype=np.float64), np.asarray(k, dtype=np.float64)], axis=1)
+                              if len(w) else np.zeros((0, 2)), dtype=torch.float64, device=dev)
+        n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n, group=group)
+        counts = [int(c.item()) for c in counts]
+        nmax = max(max(counts), 1)
+        padded = torch.zeros((nmax, 2), dtype=torch.float64, device=dev)
+        padded[:rec.shape[0]] = rec
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        allrec = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0).cpu().numpy()
+        out[mode] = (allrec[:, 0].copy(), allrec[:, 1].copy())
+    return out

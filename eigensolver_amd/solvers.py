@@ -137,6 +137,21 @@ class _WorkerSolver:
         return out
 
 
+def solve_distributed(solver, wavenumbers, n_per_band=None, modes=None, strided=True):
+    """The reference's driver block k-tiled over the ranks of the default process group (one process per GPU): every
+    rank solves its strided tile of the wavenumbers (no data-path collective), then one all-gather of the root lists
+    over RCCL.  Returns the same dict as `solver.solve` on every rank (rank-major order)."""
+    import torch.distributed as dist
+    from .distributed import gather_mode_results, tile_rows
+    ks = np.asarray(wavenumbers, dtype=np.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        mine = ks[tile_rows(len(ks), dist.get_rank(), dist.get_world_size(), strided)]
+    else:
+        mine = ks
+    local = solver.solve(mine, n_per_band, modes) if n_per_band is not None else solver.solve(mine, modes=modes)
+    return gather_mode_results(local)
+
+
 class CylinderNonUniformDensity(_WorkerSolver):
     """Density_cylinder.py (coronal, CD-C) / Density_cylinder_photospheric.py (CD-P)."""
 
