@@ -37,3 +37,37 @@ t = time.time() - t
 acc = int((roots["flag"] == 1).sum())
 print(f"find_roots: {cnt} brackets, {acc} accepted, {t*1e3:.1f} ms ({cnt*41/t/1e6:.2f} M evals/s in refine)")
 print("status histogram", torch.bincount(st.flatten().to(torch.int64), minlength=4).tolist())
+
+# K1 (closed-form slab) and K2 (closed-form cylinder) and the slab-flow propagator at BASELINE sizes
+from eigensolver_amd import SlabSteadyFlow, CylinderUniform  # noqa: E402
+
+
+def timeit(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t = time.time()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.time() - t)
+    return min(ts)
+
+
+s = SlabSteadyFlow(ctx=ctx)
+K = torch.linspace(3.5 / n, 3.5, n, dtype=torch.float64, device="cuda")
+Wv = (torch.arange(n, dtype=torch.float64, device="cuda") + 0.5) * (3.0 / n)
+for mode in (0, 2):
+    t = timeit(lambda: s.disp_rel(mode, Wv, K))
+    print(f"K1 slab analytic mode {mode}: {n}x{n} eval {t*1e3:.2f} ms -> {n*n/t/1e9:.2f} G det-evals/s, {n*n*8/t/1e9:.0f} GB/s written")
+t = timeit(lambda: s.scan(0, K, Wv, 3.0 / n, capacity=1 << 20))
+print(f"K1 scan (2 evals per cell + compaction): {t*1e3:.2f} ms -> {2*n*n/t/1e9:.2f} G det-evals/s")
+cu = CylinderUniform(q.CylinderFlow(), "kink", ctx=ctx)
+t = timeit(lambda: cu.eval_grid(k, W))
+print(f"K2 uniform cylinder closed form: {n}x{n} eval {t*1e3:.2f} ms -> {n*n/t/1e6:.1f} M det-evals/s")
+n1 = 1024
+sf = ShootProblem(q.SlabFlow(U_i0=0.35, width=1.5), "sausage", ctx=ctx)
+k1 = torch.linspace(0.05, 3.5, n1, dtype=torch.float64, device="cuda")
+W1 = 1.4 + (torch.arange(n1, dtype=torch.float64, device="cuda") + 0.5) * (2.45 - 1.4) / n1
+t = timeit(lambda: sf.eval_grid(k1, W1))
+print(f"K3 slab flow (config 2, 1024x1024, N=500): {t*1e3:.2f} ms -> {n1*n1/t/1e6:.1f} M det-evals/s")
