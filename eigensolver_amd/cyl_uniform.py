@@ -20,8 +20,12 @@ class CylinderUniform:
     def eval_grid(self, k, w, w_mode=1, want_rel=False):
         import torch
         dev = f"cuda:{self.ctx.device}"
-        dk = torch.as_tensor(np.ascontiguousarray(k, dtype=np.float64).reshape(-1), device=dev)
-        dw = torch.as_tensor(np.ascontiguousarray(w, dtype=np.float64), device=dev)
+        def to_dev(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=torch.float64).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+        dk = to_dev(k).reshape(-1)
+        dw = to_dev(w)
         nk = dk.numel()
         nw = dw.shape[-1] if w_mode == 2 else dw.numel()
         D = torch.empty((nk, nw), dtype=torch.float64, device=dev)
