@@ -191,7 +191,7 @@ def main():
                           "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                           "flops_per_eval": FLOPS_PER_STEP * nsteps},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:          # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(eq, m, k.cpu().numpy(), W.cpu().numpy())
         print(json.dumps(out), flush=True)
     if world > 1:
