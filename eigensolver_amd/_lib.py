@@ -126,7 +126,8 @@ class RootTable(C.Structure):
 
 class WorkerSpec(C.Structure):
     _fields_ = [("tol_percent", C.c_double), ("min_len", C.c_int32), ("itt_cap", C.c_int32),
-                ("reset_loop_ws_each_iter", C.c_int32), ("break_on_accept", C.c_int32)]
+                ("reset_loop_ws_each_iter", C.c_int32), ("break_on_accept", C.c_int32),
+                ("stale_ext_const", C.c_int32), ("reserved", C.c_int32)]
 
 
 def _sig_shoot(lib):

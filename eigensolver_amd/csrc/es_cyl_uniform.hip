@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void cyl_uniform_kernel(ShootDev P, UniDev U, 
     if (iw >= nw) continue;
     const double k = kv[row];
     const double w = pick_w_u(wv, w_mode, k, row, nw, iw);
-    const Exterior X = exterior_cylinder(P, k, w);
+    const Exterior X = exterior_cylinder(P, k, w, w);
     const double k2 = k * k;
     const double Om = w - k * U.U_i;
     const double Om2 = Om * Om;

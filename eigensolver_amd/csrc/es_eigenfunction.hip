@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void eigen_interior_kernel(ShootDev P, const do
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
   SignTrack trk;
   double b[NB], e[NE], e2[NE];
-  const ExteriorLite X = exterior_lite(P, k, w);
+  const ExteriorLite X = exterior_lite(P, k, w, w);
   // (1) adjoint march: the row of the transfer matrix picked by the far-end condition -> boundary state (u_b, v_b)
   load_base<FAM>(P, 2 * nsteps, b);
   make_entry<FAM>(b, s, e);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void eigen_exterior_kernel(ShootDev P, const d
   const int i = (int)(t / n_ext), j = (int)(t - (long)i * n_ext);
   const double k = kv[i], w = wv[i];
   const bool cyl = (P.family == FAM_CYL0 || P.family == FAM_CYLT);
-  const Exterior X = cyl ? exterior_cylinder(P, k, w) : exterior_slab(P, k, w);
+  const Exterior X = cyl ? exterior_cylinder(P, k, w, w) : exterior_slab(P, k, w);
   const double sgn = (P.xb < 0.0) ? -1.0 : 1.0;
   const double R = P.R_factor / k;
   // np.linspace(sgn*R, sgn*1, n_ext)[j]

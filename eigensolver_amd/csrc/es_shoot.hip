@@ -54,7 +54,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
       // and only its three results per point are carried through the march (no call frame, no scratch)
       ExteriorLite X[PTS];
 #pragma unroll
-      for (int p = 0; p < PTS; ++p) X[p] = exterior_lite(P, k, w[p]);
+      for (int p = 0; p < PTS; ++p) X[p] = exterior_lite(P, k, w[p], w[p]);
       // adjoint march: chunks from the far end of the interior back to the boundary
       const int nchunks = (nsteps + CH - 1) / CH;
       for (int c = nchunks - 1; c >= 0; --c) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void shoot_points_kernel(ShootDev P, const dou
   const double k = in ? kv[i] : 1.0;
   const double w = in ? wv[i] : 1.0;
   double D, rel; uint8_t st;
-  shoot_point<FAM>(P, k, w, D, rel, st);
+  shoot_point<FAM>(P, k, w, w, D, rel, st);
   if (in) {
     Dout[i] = D;
     stout[i] = st;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
   double D, rel; uint8_t st;
   for (int it = 0; it < n_rounds; ++it) {
     const double x = lo + (hi - lo) * frac;
-    shoot_point<FAM>(P, k, x, D, rel, st);
+    shoot_point<FAM>(P, k, x, x, D, rel, st);
     const bool diff = (D * flo < 0.0);                 // NaN products compare false, as in the reference
     const unsigned bits = (unsigned)((__ballot(diff) >> (8 * g)) & 0xFFull);
     const int first = bits ? (__ffs((int)bits) - 1) : 8;         // first point whose sign differs from D(lo)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
     if (first > 0) { lo = x_lo; flo = (d_lo_new == d_lo_new) ? d_lo_new : flo; }
   }
   const double root = lo + (hi - lo) * 0.5;
-  shoot_point<FAM>(P, k, root, D, rel, st);
+  shoot_point<FAM>(P, k, root, root, D, rel, st);
   if (in && j == 0) {
     tab.d_w[i] = root;
     tab.d_w_lo[i] = lo;

@@ -302,12 +302,14 @@ struct Exterior {
   int status;       // ES_PT_OK / LEAKY / NONFINITE
 };
 
-__device__ __forceinline__ Exterior exterior_cylinder(const ShootDev& P, double k, double w) {
+// w_cst: frequency at which xi_e_const is evaluated (= w everywhere except inside CR-SF's locate_sausage, which reads
+// the enclosing loop's stale value)
+__device__ __forceinline__ Exterior exterior_cylinder(const ShootDev& P, double k, double w, double w_cst) {
   Exterior X;
   const double k2 = k * k, w2 = w * w;
   X.Oe = w;
   X.m_e = ((k2 * P.vAe2 - w2) * (k2 * P.ce2 - w2)) / (P.Se * (k2 * P.cTe2 - w2));     // CF:699
-  X.cst = -1.0 / (P.rho_e * (k2 * P.vAe2 - w2));                                     // CF:702
+  X.cst = -1.0 / (P.rho_e * (k2 * P.vAe2 - w_cst * w_cst));                          // CF:702
   X.yb = X.dyb = NAN;
   if (X.m_e < 0.0) { X.status = ES_PT_LEAKY; return X; }
   if (!(X.m_e > 0.0) || !isfinite(X.m_e) || !isfinite(X.cst)) { X.status = ES_PT_NONFINITE; return X; }

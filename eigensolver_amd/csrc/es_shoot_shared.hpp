@@ -34,8 +34,8 @@ struct ExteriorLite {
 
 // Evaluated BEFORE the RK4 march (few live registers), inlined: the Bessel series / continued fraction need ~100
 // VGPRs of their own, which then overlap with nothing; only the three results are carried through the loop.
-__device__ __forceinline__ ExteriorLite exterior_lite(const ShootDev& P, double k, double w) {
-  const Exterior X = (P.family == FAM_CYL0 || P.family == FAM_CYLT) ? exterior_cylinder(P, k, w) : exterior_slab(P, k, w);
+__device__ __forceinline__ ExteriorLite exterior_lite(const ShootDev& P, double k, double w, double w_cst) {
+  const Exterior X = (P.family == FAM_CYL0 || P.family == FAM_CYLT) ? exterior_cylinder(P, k, w, w_cst) : exterior_slab(P, k, w);
   ExteriorLite L;
   L.outer = X.cst * X.dyb;
   L.yb = X.yb;
@@ -57,8 +57,8 @@ __device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& 
 
 // One (k, omega) pair per lane.  Base-table indices are wave-uniform -> scalar loads.
 template <int FAM>
-__device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double& D, double& rel,
-                                            uint8_t& st) {
+__device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
+                                            double& rel, uint8_t& st) {
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr int NB = FamTraits<FAM>::NB;
   constexpr bool DIAG = FamTraits<FAM>::DIAG;
@@ -67,7 +67,7 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
   SignTrack trk;
   double b[NB], e[NE], e2[NE];
-  const ExteriorLite X = exterior_lite(P, k, w);
+  const ExteriorLite X = exterior_lite(P, k, w, w_cst);
   // adjoint march from the last node back to the boundary (same arithmetic as the grid kernel)
   load_base<FAM>(P, 2 * nsteps, b);
   make_entry<FAM>(b, s, e);

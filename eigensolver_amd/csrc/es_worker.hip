@@ -27,7 +27,7 @@ struct Frame {
 
 struct WorkerArgs {
   double tol;
-  int min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept;
+  int min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, stale_ext_const;
   int ntasks, nfreq, max_roots, stack_depth;
   const double* k;
   const double* freq;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   double main_prev = 0.0, loop_prev = 0.0;           // *_diff_check[-1], *_diff_loop_check[-1] (start [0])
   int all_len = 0, loop_len = 0;                     // len(all_ws), len(loop_ws)
   double all_m1 = 0.0, all_m2 = 0.0, loop_m1 = 0.0, loop_m2 = 0.0;   // [-1], [-2]
+  double w_stale = 1.0;                              // grid frequency that opened the current refinement (CR-SF:617)
   bool done = !live;
   // hard bound on the work of one task (every loop iteration below consumes one evaluation or pops a frame)
   const long eval_cap = 3L * (a.itt_cap + 2) * (a.nfreq + 1);
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
         } else if (sign < 0.0 && all_len > a.min_len) {           // CF:822-829
           Frame f{all_m2, all_m2 + (all_m1 - all_m2) * 0.5, all_m1, 0, 0};   // np.linspace(all_ws[-2], all_ws[-1], 3)
           all_len = 0;
+          w_stale = w;
           stk[0] = f;
           sp = 1;
         }
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
     if (!__any(need)) break;
     // ---- one determinant evaluation per lane (dummy for lanes that do not need one) ---------------------------
     double d, rel; uint8_t st;
-    shoot_point<FAM>(P, k, w_eval, d, rel, st);
+    shoot_point<FAM>(P, k, w_eval, a.stale_ext_const ? w_stale : w_eval, d, rel, st);
     if (need) {
       Frame& f = stk[sp - 1];
       ++f.kk;
@@ -169,6 +171,7 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
     WorkerArgs a;
     a.tol = spec->tol_percent; a.min_len = spec->min_len; a.itt_cap = spec->itt_cap;
     a.reset_loop_ws_each_iter = spec->reset_loop_ws_each_iter; a.break_on_accept = spec->break_on_accept;
+    a.stale_ext_const = spec->stale_ext_const;
     a.ntasks = ntasks; a.nfreq = nfreq; a.max_roots = max_roots; a.stack_depth = depth;
     a.k = d_k; a.freq = d_freq; a.D = D; a.rel = rel; a.st = st; a.stack = stack;
     a.roots = d_roots; a.nroots = d_nroots; a.nevals = d_nevals;

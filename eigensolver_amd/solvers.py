@@ -30,7 +30,7 @@ from .shooting import ShootProblem
 class _WorkerSolver:
     """Common machinery: problems per mode, batched worker runs, the reference-signature entry points."""
 
-    # (tol_percent, min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, accept_norm) per mode
+    # (tol_percent, min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, accept_norm[, stale_ext_const]) per mode
     WORKER = {}
     modes = ("sausage", "kink")
 
@@ -69,7 +69,8 @@ class _WorkerSolver:
 
     def worker_spec(self, mode, tol=None):
         t = self.WORKER[mode]
-        return _lib.WorkerSpec(float(t[0] if tol is None else tol), int(t[1]), int(t[2]), int(t[3]), int(t[4]))
+        stale = int(t[6]) if len(t) > 6 else 0
+        return _lib.WorkerSpec(float(t[0] if tol is None else tol), int(t[1]), int(t[2]), int(t[3]), int(t[4]), stale, 0)
 
     def run_batch(self, mode, wavenumbers, freqs, tol=None, max_roots=None, return_evals=False):
         """Many worker calls at once: wavenumbers[t], freqs[t, :] -> list of root lists (one per task)."""
@@ -191,8 +192,8 @@ class CylinderRotationalFlow(_WorkerSolver):
     def __init__(self, v_twist=0.25, power=0.8, variant="kink_fast", ctx=None, **kw):
         spec = {"kink_fast": ("kink", (2.5, 2, 500, 0, 1, 0), 1e-3),        # CR-KF:435, :464, :722
                 "kink_slow": ("kink", (3.0, 2, 500, 0, 1, 1), 1e-3),        # CR-KS:441, :468, :722
-                "sausage": ("sausage", (1.5, 2, 250, 0, 0, 0), 1e-2),       # CR-SF:419, :475, r_ax 0.01 (:157)
-                "sausage_slow": ("sausage", (4.5, 2, 250, 0, 0, 0), 1e-2)}[variant]
+                "sausage": ("sausage", (1.5, 2, 250, 0, 0, 0, 1), 1e-2),    # CR-SF:419, :475, r_ax 0.01 (:157), stale xi_e_const (:558)
+                "sausage_slow": ("sausage", (4.5, 2, 250, 0, 0, 0, 1), 1e-2)}[variant]
         self.modes = (spec[0],)
         self.WORKER = {spec[0]: spec[1]}
         self.variant = variant

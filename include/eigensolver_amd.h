@@ -186,6 +186,9 @@ typedef struct es_worker_spec {
   int32_t itt_cap;                 /* `if itt_num > cap: break`  (100 ... 500)                              */
   int32_t reset_loop_ws_each_iter; /* slab sausage workers clear loop_ws at every main iteration (SF-U:536) */
   int32_t break_on_accept;         /* CR kink workers: `break` after the first accepted grid point (CR-KF:722) */
+  int32_t stale_ext_const;         /* CR sausage workers: locate_sausage() uses the enclosing loop's xi_e_const, i.e. the
+                                      value at the grid frequency that opened the bracket (CR-SF:558 vs :617)            */
+  int32_t reserved;
 } es_worker_spec;
 
 /* Task t: wavenumber d_k[t], frequencies d_freq[t*nfreq .. t*nfreq+nfreq).  Roots of task t are written to

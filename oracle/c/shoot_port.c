@@ -278,12 +278,12 @@ static void rk4_adjoint(int diag, double* p, double* q, const coef* B0, const co
 
 typedef struct { double m_e, cst, yb, dyb, Oe; int status; } exterior;
 
-static exterior ext_cyl(const port_problem* P, double k, double w) {
+static exterior ext_cyl(const port_problem* P, double k, double w, double w_cst) {
   exterior X;
   double k2 = k * k, w2 = w * w;
   X.Oe = w;
   X.m_e = ((k2 * P->vAe2 - w2) * (k2 * P->ce2 - w2)) / (P->Se * (k2 * P->cTe2 - w2));
-  X.cst = -1.0 / (P->rho_e * (k2 * P->vAe2 - w2));
+  X.cst = -1.0 / (P->rho_e * (k2 * P->vAe2 - w_cst * w_cst));
   X.yb = X.dyb = NAN;
   if (X.m_e < 0.0) { X.status = ES_PT_LEAKY; return X; }
   if (!(X.m_e > 0.0) || !isfinite(X.m_e) || !isfinite(X.cst)) { X.status = ES_PT_NONFINITE; return X; }
@@ -334,8 +334,11 @@ static exterior ext_slab(const port_problem* P, double k, double w) {
   return X;
 }
 
-/* One determinant evaluation.  Returns status; *D, *rel as the product defines them. */
-int port_eval(const port_problem* P, double k, double w, double* D, double* rel) {
+/* One determinant evaluation.  Returns status; *D, *rel as the product defines them.  w_cst: frequency at which the
+ * exterior constant xi_e_const is taken (= w except inside CR-SF's locate_sausage, see oracle/workers.py). */
+int port_eval2(const port_problem* P, double k, double w, double w_cst, double* D, double* rel);
+int port_eval(const port_problem* P, double k, double w, double* D, double* rel) { return port_eval2(P, k, w, w, D, rel); }
+int port_eval2(const port_problem* P, double k, double w, double w_cst, double* D, double* rel) {
   kscal s;
   s.k = k; s.k2 = k * k; s.m = (double)P->m; s.m2 = s.m * s.m;
   s.kc2 = s.k2 * P->c2_i; s.kvA2 = s.k2 * P->vA2_i; s.kcT2 = s.k2 * P->cT2_i;
@@ -357,7 +360,7 @@ int port_eval(const port_problem* P, double k, double w, double* D, double* rel)
     rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
     B0 = B1;
   }
-  exterior X = (P->family <= 1) ? ext_cyl(P, k, w) : ext_slab(P, k, w);
+  exterior X = (P->family <= 1) ? ext_cyl(P, k, w, w_cst) : ext_slab(P, k, w);
   double outer, inner;
   if (P->family <= 1) {
     double Pb = X.yb, xi_e = X.cst * X.dyb, Xb;

@@ -43,6 +43,7 @@ def lib():
         L.port_create.argtypes = [C.POINTER(ShootDesc), C.POINTER(Profiles)]
         L.port_destroy.argtypes = [vp]
         L.port_eval.argtypes = [vp, d, d, C.POINTER(d), C.POINTER(d)]
+        L.port_eval2.argtypes = [vp, d, d, d, C.POINTER(d), C.POINTER(d)]
         L.port_eval_points.argtypes = [vp, vp, vp, l, vp, vp, vp, i]
         L.port_eval_grid.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp, i]
         L.port_find_roots.restype = l

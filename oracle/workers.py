@@ -20,8 +20,8 @@ Quirks that are reproduced on purpose (they decide which roots the reference rep
   * loop_ws is not cleared when a locate_* chain ends without acceptance, so later chains see stale entries
     (slab sausage workers clear it at every main-loop iteration, SF-U:536);
   * rotational kink workers stop the main loop at the first accepted grid point (`break`, CR-KF:722).
-Not reproduced: CR-SF's locate_sausage uses a stale outer xi_e_const (defined only at CR-SF:617) -- the restatement
-evaluates xi_e_const at the point itself, as every other worker does.
+  * CR-SF / CR-SS: locate_sausage() never assigns xi_e_const and therefore reads the enclosing main loop's value
+    (CR-SF:617), i.e. the constant at the grid frequency that opened the refinement (`stale_ext_const`).
 
 Pinned by tests/test_oracle_workers.py: replaying the reference's own mismatch values (golden traces) through this
 state machine must request exactly the reference's sequence of frequencies and report exactly its roots.
@@ -41,6 +41,7 @@ class WorkerSpec:
     reset_loop_ws_each_iter: bool = False   # slab sausage workers: loop_ws[:] = [] at every main-loop iteration
     break_on_accept: bool = False           # CR kink workers: break the main loop at the first accepted grid point
     accept_norm_outer_only: bool = False    # CR-KS:722 divides by |xi_e| instead of max(|xi_e|, |xi_i|)
+    stale_ext_const: bool = False           # CR-SF/SS: locate_sausage reads the enclosing loop's xi_e_const (CR-SF:558 vs :617)
 
 
 # the checked-in values of every worker (file:line of tolerance / cap)
@@ -58,8 +59,8 @@ SPECS = {
     ("CF", "kink"): WorkerSpec(6.0, 2, 250), ("CF", "sausage"): WorkerSpec(6.0, 2, 250),       # CF:530, :566
     ("CR-KF", "kink"): WorkerSpec(2.5, 2, 500, break_on_accept=True),                 # CR-KF:435, :464
     ("CR-KS", "kink"): WorkerSpec(3.0, 2, 500, break_on_accept=True, accept_norm_outer_only=True),  # CR-KS:441, :722
-    ("CR-SF", "sausage"): WorkerSpec(1.5, 2, 250),                                    # CR-SF:419, :475
-    ("CR-SS", "sausage"): WorkerSpec(4.5, 2, 250),                                    # CR-SS:423, :479
+    ("CR-SF", "sausage"): WorkerSpec(1.5, 2, 250, stale_ext_const=True),              # CR-SF:419, :475, :558
+    ("CR-SS", "sausage"): WorkerSpec(4.5, 2, 250, stale_ext_const=True),              # CR-SS:423, :479, :562
 }
 
 
@@ -67,7 +68,8 @@ class WorkerRun:
     """One call `worker(wavenumber, ws_sink, ks_sink, freq)`.
 
     evaluate(k, w) -> (status, d, outer, inner):  status ST_LEAKY means m_e < 0 (point skipped by the reference);
-    any other status means the reference evaluates the point (d may be NaN)."""
+    any other status means the reference evaluates the point (d may be NaN).  With spec.stale_ext_const the evaluator
+    is called as evaluate(k, w, w_cst) inside locate(), w_cst = grid frequency that opened the refinement."""
 
     def __init__(self, spec, evaluate, k):
         self.spec, self.evaluate, self.k = spec, evaluate, float(k)
@@ -77,6 +79,7 @@ class WorkerRun:
         self.loop_prev = 0.0           # *_diff_loop_check[-1]
         self.all_ws = []
         self.loop_ws = []
+        self.w_stale = None
 
     def _accepts(self, d, outer, inner):
         s = self.spec
@@ -86,7 +89,10 @@ class WorkerRun:
         return rel < s.tol
 
     def _eval(self, w, where):
-        st, d, outer, inner = self.evaluate(self.k, float(w))
+        if where == "loop" and self.spec.stale_ext_const:
+            st, d, outer, inner = self.evaluate(self.k, float(w), self.w_stale)
+        else:
+            st, d, outer, inner = self.evaluate(self.k, float(w))
         if st != ST_LEAKY:
             self.requested.append((where, float(w)))
         return st, d, outer, inner
@@ -132,6 +138,7 @@ class WorkerRun:
             elif sign < 0 and len(self.all_ws) > s.min_len:
                 omega = np.linspace(self.all_ws[-2], self.all_ws[-1], 3)
                 self.all_ws = []
+                self.w_stale = float(w)
                 self.locate(omega, 0)
         return self.roots
 

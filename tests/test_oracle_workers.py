@@ -27,8 +27,10 @@ def _replay_evaluator(prob, call):
         slope = ext[2] if len(ext) == 4 else ext[1]
         table.setdefault(ev["omega"], []).append((ev["d"], slope))
 
-    def evaluate(k, w):
+    def evaluate(k, w, w_cst=None):
         m_e, cst = prob.exterior(k, w)[:2]
+        if w_cst is not None:                      # CR-SF: xi_e_const of the grid point that opened the refinement
+            cst = prob.exterior(k, w_cst)[1]
         if m_e < 0:
             return W.ST_LEAKY, float("nan"), float("nan"), float("nan")
         q = table[w]                             # KeyError = the state machine asked for a point the reference never evaluated

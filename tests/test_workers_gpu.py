@@ -50,9 +50,9 @@ def _port_evaluator(solver, mode):
     L = lib()
     accept_outer = bool(prob.desc.accept_norm)
 
-    def evaluate(k, w):
+    def evaluate(k, w, w_cst=None):
         d, rel = C.c_double(), C.c_double()
-        st = L.port_eval(pp.h, k, w, C.byref(d), C.byref(rel))
+        st = L.port_eval2(pp.h, k, w, w if w_cst is None else w_cst, C.byref(d), C.byref(rel))
         if st == 1:
             return OW.ST_LEAKY, float("nan"), float("nan"), float("nan")
         # the state machine only needs rel = 100|d|/norm: hand it (d, outer, inner) with that ratio
@@ -146,7 +146,7 @@ def test_driver_block_layout(es_ctx):
 
 ROOTSET_SOLVERS = {
     "CF_flow": ("CF_flow", "CF"), "CF_uniform": ("CF_uniform", "CF"), "CDC_w095": ("CDC_w095", "CD-C"),
-    "SFG_flow": ("SFG_flow", "SF-G"), "CRKS": ("CRKS", "CR-KS"),
+    "SFG_flow": ("SFG_flow", "SF-G"), "CRKS": ("CRKS", "CR-KS"), "CRSF": ("CRSF", "CR-SF"),
 }
 
 

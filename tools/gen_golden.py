@@ -198,6 +198,7 @@ ROOTSETS = {
     "SFG_flow": ("SF-G", [("dx=1e5", "dx=1.5"), ("U_i0 = 0.9*vA_i", "U_i0 = 0.35*vA_i")],
                  [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.4, 2.45)], 40, ("kink", "sausage")),
     "CRKS": ("CR-KS", [], [0.6, 1.0, 1.5, 2.0, 3.0], [(0.7, 0.99), (1.21, 1.44)], 30, ("kink",)),
+    "CRSF": ("CR-SF", [], [0.8, 1.2, 1.6, 2.0, 2.5, 3.0, 3.5], [(1.05, 1.4), (0.7, 0.99)], 30, ("sausage",)),
 }
 
 
