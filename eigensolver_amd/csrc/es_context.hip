@@ -3,6 +3,18 @@
 
 extern "C" int es_abi_version(void) { return ES_ABI_VERSION; }
 
+extern "C" int es_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(es_slab_analytic_params);
+    case 1: return (int)sizeof(es_shoot_desc);
+    case 2: return (int)sizeof(es_profiles);
+    case 3: return (int)sizeof(es_root_table);
+    case 4: return (int)sizeof(es_worker_spec);
+    case 5: return (int)sizeof(es_cyl_uniform_params);
+    default: return -1;
+  }
+}
+
 extern "C" const char* es_status_string(int s) {
   switch (s) {
     case ES_SUCCESS: return "success";

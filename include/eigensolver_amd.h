@@ -55,6 +55,10 @@ int es_context_create(int device, void* stream, es_context** out);
 int es_context_destroy(es_context* ctx);
 const char* es_last_error(const es_context* ctx);
 int es_context_synchronize(es_context* ctx);
+/* sizeof() of the ABI structs as this library was compiled, for binding self-checks:
+ * which = 0 es_slab_analytic_params, 1 es_shoot_desc, 2 es_profiles, 3 es_root_table, 4 es_worker_spec,
+ * 5 es_cyl_uniform_params; -1 for an unknown index. */
+int es_abi_sizeof(int which);
 
 /* ========================================================================================================
  * (1) Analytic slab dispersion relations with steady flow and their sign-change scan.

@@ -40,3 +40,19 @@ def test_no_cpu_fallback_without_device():
     lib = _lib.load()
     h = ctypes.c_void_p()
     assert lib.es_context_create(0, None, ctypes.byref(h)) != 0
+
+
+def test_ctypes_struct_layouts_match_the_library():
+    """The ctypes mirrors in eigensolver_amd/_lib.py (and the oracle's mirror of es_shoot_desc) have the size the C
+    compiler gave the structs of include/eigensolver_amd.h."""
+    from eigensolver_amd import _lib, build
+    from oracle import port
+    lib = ctypes.CDLL(build.build())
+    lib.es_abi_sizeof.restype = ctypes.c_int
+    lib.es_abi_sizeof.argtypes = [ctypes.c_int]
+    mirrors = [_lib.SlabAnalyticParams, _lib.ShootDesc, _lib.Profiles, _lib.RootTable, _lib.WorkerSpec,
+               _lib.CylUniformParams]
+    for i, m in enumerate(mirrors):
+        assert lib.es_abi_sizeof(i) == ctypes.sizeof(m), (i, m.__name__, lib.es_abi_sizeof(i), ctypes.sizeof(m))
+    assert lib.es_abi_sizeof(1) == ctypes.sizeof(port.ShootDesc) and lib.es_abi_sizeof(2) == ctypes.sizeof(port.Profiles)
+    assert lib.es_abi_sizeof(99) == -1
