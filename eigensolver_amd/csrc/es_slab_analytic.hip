@@ -61,17 +61,47 @@ __device__ __forceinline__ double disp_rel_dyn(int mode, const SlabP& p, double 
   }
 }
 
-// grid: x = ceil(nW / 256) blocks along W, y = K rows.  One point per lane; K is block-uniform.
+// Everything except the tanh / tan factor depends on W only (m0, me, the density/speed prefactors): it is computed
+// once per lane and reused for K_TILE rows, so a grid point costs one multiply, one tanh/tan, the products and the
+// final division -- the same operations in the same order as disp_rel<MODE>() (bit-identical results).
+//   sausage: ((num*m0) * tanh(K*m0)) / (me*di) + 1        kink: (num*m0) / ((tanh(K*m0)*me)*di) + 1
+template <int MODE>
+struct SlabColumn {
+  double root;     // m0 (surface modes) or n0 (body modes)
+  double A;        // num * root
+  double me, di;
+  __device__ __forceinline__ void init(const SlabP& p, double W) {
+    me = sqrt(me_arg(p, W));
+    const double num = p.R1 * (sq(p.vA_e) - sq(W - p.mach_e));
+    di = sq(p.vA_i) - sq(W - p.mach_i);
+    const double arg = m0_arg(p, W);
+    root = (MODE == ES_SLAB_SAUSAGE || MODE == ES_SLAB_KINK) ? sqrt(arg) : sqrt(fabs(arg));
+    A = num * root;
+  }
+  __device__ __forceinline__ double eval(double K) const {
+    if (MODE == ES_SLAB_SAUSAGE) return A * tanh(K * root) / (me * di) + 1.0;
+    if (MODE == ES_SLAB_KINK) return A / (tanh(K * root) * me * di) + 1.0;
+    if (MODE == ES_SLAB_SAUSAGE_BODY) return A * tan(K * root) / (me * di) - 1.0;
+    return A / (tan(K * root) * me * di) + 1.0;
+  }
+};
+
+constexpr int K_TILE = 16;
+
+// grid: x = ceil(nW / 256) blocks along W, y = tiles of K_TILE rows.  W on the lanes (coalesced 512 B stores per wave),
+// K is workgroup-uniform (scalar load).
 template <int MODE>
 __global__ __launch_bounds__(256) void slab_eval_kernel(SlabP p, const double* __restrict__ Kv, int nK,
                                                         const double* __restrict__ Wv, int nW,
                                                         double* __restrict__ D) {
   const int iW = blockIdx.x * 256 + threadIdx.x;
-  for (int iK = blockIdx.y; iK < nK; iK += gridDim.y) {
-    if (iW < nW) {
-      const double K = Kv[iK];
-      D[(size_t)iK * nW + iW] = disp_rel<MODE>(p, Wv[iW], K);
-    }
+  if (iW >= nW) return;
+  SlabColumn<MODE> col;
+  col.init(p, Wv[iW]);
+  for (int tile = blockIdx.y; tile * K_TILE < nK; tile += gridDim.y) {
+    const int k0 = tile * K_TILE;
+    const int k1 = (k0 + K_TILE < nK) ? k0 + K_TILE : nK;
+    for (int iK = k0; iK < k1; ++iK) D[(size_t)iK * nW + iW] = col.eval(Kv[iK]);
   }
 }
 
@@ -149,7 +179,8 @@ extern "C" int es_slab_analytic_eval(es_context* ctx, const es_slab_analytic_par
   if (nK == 0 || nW == 0) return ES_SUCCESS;
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const SlabP sp = to_dev(p);
-  dim3 grid((nW + 255) / 256, nK < 65535 ? nK : 65535), block(256);
+  const int ntiles = (nK + K_TILE - 1) / K_TILE;
+  dim3 grid((nW + 255) / 256, ntiles < 65535 ? ntiles : 65535), block(256);
   switch (mode) {
     case ES_SLAB_SAUSAGE: hipLaunchKernelGGL(slab_eval_kernel<ES_SLAB_SAUSAGE>, grid, block, 0, ctx->stream, sp, d_K, nK, d_W, nW, d_D); break;
     case ES_SLAB_KINK: hipLaunchKernelGGL(slab_eval_kernel<ES_SLAB_KINK>, grid, block, 0, ctx->stream, sp, d_K, nK, d_W, nW, d_D); break;
