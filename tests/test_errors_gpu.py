@@ -1,0 +1,62 @@
+"""Error behaviour of the C ABI on a device: invalid arguments are reported through return codes / EsError with a
+message, never by crashing or by silently computing something else."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_invalid_arguments_are_rejected(es_ctx):
+    import torch
+    from eigensolver_amd import _lib, ShootProblem, equilibrium as q
+    lib = es_ctx.lib
+    # unknown mode of the analytic kernel
+    p = _lib.SlabAnalyticParams(1, 2 / 3, 0, 0.75, 0, -0.15, 2.27, 0.55, 0.0)
+    K = torch.ones(4, dtype=torch.float64, device="cuda")
+    D = torch.empty(16, dtype=torch.float64, device="cuda")
+    assert lib.es_slab_analytic_eval(es_ctx.handle, C.byref(p), 7, _lib.ptr(K), 4, _lib.ptr(K), 4, _lib.ptr(D)) == 1
+    assert b"mode" in lib.es_last_error(es_ctx.handle)
+    assert lib.es_slab_analytic_eval(es_ctx.handle, C.byref(p), 0, _lib.ptr(K), -1, _lib.ptr(K), 4, _lib.ptr(D)) == 1
+    assert lib.es_slab_analytic_eval(es_ctx.handle, C.byref(p), 0, None, 4, _lib.ptr(K), 4, _lib.ptr(D)) == 1
+    # problem creation: bad geometry / node count / boundary / missing profiles
+    eq = q.CylinderFlow()
+    from eigensolver_amd.shooting import make_desc
+    d, prof = make_desc(eq, "kink")
+    pr = _lib.Profiles()
+    keep = {k: np.ascontiguousarray(v) for k, v in prof.items()}
+    for name in _lib._PROFILE_FIELDS:
+        a = keep.get(name)
+        setattr(pr, name, a.ctypes.data if a is not None else None)
+    h = C.c_void_p()
+    for field, bad in (("geometry", 9), ("n_nodes", 1), ("x_boundary", 0.5), ("axis_bc", 5), ("c1_power", 3)):
+        d2 = _lib.ShootDesc.from_buffer_copy(d)
+        setattr(d2, field, bad)
+        assert lib.es_problem_create(es_ctx.handle, C.byref(d2), C.byref(pr), C.byref(h)) == 1, field
+    pr2 = _lib.Profiles()
+    assert lib.es_problem_create(es_ctx.handle, C.byref(d), C.byref(pr2), C.byref(h)) == 1       # no profiles
+    # twisted profile handed to the un-twisted geometry
+    tw = q.CylinderRotation()
+    d3, prof3 = make_desc(tw, "kink")
+    d3.geometry = 0
+    keep3 = {k: np.ascontiguousarray(v) for k, v in prof3.items()}
+    pr3 = _lib.Profiles()
+    for name in _lib._PROFILE_FIELDS:
+        a = keep3.get(name)
+        setattr(pr3, name, a.ctypes.data if a is not None else None)
+    assert lib.es_problem_create(es_ctx.handle, C.byref(d3), C.byref(pr3), C.byref(h)) == 1
+    # evaluation entry points
+    gp = ShootProblem(eq, "kink", ctx=es_ctx)
+    with pytest.raises(_lib.EsError):
+        gp.eval_grid([1.0], [3.0], w_mode=7)
+    st = torch.empty(1, dtype=torch.uint8, device="cuda")
+    assert lib.es_shoot_eval_points(es_ctx.handle, None, _lib.ptr(K), _lib.ptr(K), 1, _lib.ptr(D), None, _lib.ptr(st)) == 1
+    ws = _lib.WorkerSpec(1.0, -1, 10, 0, 0, 0, 0)
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.es_worker_run(es_ctx.handle, gp.handle, C.byref(ws), _lib.ptr(K), 1, _lib.ptr(K), 1, _lib.ptr(D),
+                             _lib.ptr(n), 4, None) == 1
+    # the context is still usable after errors
+    Dg, stg = gp.eval_grid([1.0, 2.0], [3.0, 3.5])
+    assert torch.isfinite(Dg).all()
+    gp.close()
