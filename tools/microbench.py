@@ -71,3 +71,14 @@ k1 = torch.linspace(0.05, 3.5, n1, dtype=torch.float64, device="cuda")
 W1 = 1.4 + (torch.arange(n1, dtype=torch.float64, device="cuda") + 0.5) * (2.45 - 1.4) / n1
 t = timeit(lambda: sf.eval_grid(k1, W1))
 print(f"K3 slab flow (config 2, 1024x1024, N=500): {t*1e3:.2f} ms -> {n1*n1/t/1e6:.1f} M det-evals/s")
+
+# twisted / rotational family (configs[4]): general coefficient set, N = 2000 nodes
+n2 = 2048
+rot = ShootProblem(q.CylinderRotation(v_twist=0.1, power=1.0), "kink", ctx=ctx)
+k2 = torch.linspace(0.25, 4.0, n2, dtype=torch.float64, device="cuda")
+W2 = 0.7 + (torch.arange(n2, dtype=torch.float64, device="cuda") + 0.5) * (1.45 - 0.7) / n2
+for variant in ("0", "1", "2"):
+    os.environ["ES_GRID_VARIANT"] = variant
+    t = timeit(lambda: rot.eval_grid(k2, W2), reps=3)
+    print(f"K3 rotational (FAM_CYLT, {n2}x{n2}, N=2000) variant {variant}: {t*1e3:.1f} ms -> {n2*n2/t/1e6:.1f} M det-evals/s")
+del os.environ["ES_GRID_VARIANT"]
