@@ -28,8 +28,9 @@ sys.path.insert(0, ROOT)
 
 NK = NW = 4096
 W_LO, W_HI = 0.8944271909999159, 5.0          # (cT_i0, vA_e) of the coronal cylinder
-N_BISECT = 24                                 # bracket width <= 2^-24 * k dW ~ 6e-11 omega -> midpoint error < 1e-10 omega
-REFINE_ROUNDS = 8                             # 9-section rounds: 9^8 >= 2^24 (8 evaluations per round and bracket)
+N_BISECT = 16                                 # bracket narrowed by >= 2^16 (6 rounds of 9-section: 9^6 = 5.3e5), then
+REFINE_ROUNDS = 6                             # two regula-falsi polish steps -> |d omega/omega| ~ 1e-16 (8 evals per round)
+REFINE_POLISH = 2
 TOL_PERCENT = 1e-3
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
@@ -164,7 +165,7 @@ def main():
     grid_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
 
     if rank == 0:
-        evals_per_step = world * NK * NW + brackets_total * (8 * REFINE_ROUNDS + 1)
+        evals_per_step = world * NK * NW + brackets_total * (8 * REFINE_ROUNDS + REFINE_POLISH)
         value = evals_per_step * a.steps / dt
         grid_evals = NK * NW
         achieved = grid_evals * BYTES_PER_EVAL / (grid_ms * 1e-3) / 1e9
@@ -178,7 +179,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Cylinder / non-uniform (Gaussian) axial flow, coronal, kink-type m = rank+1, "
                                    "4096x4096 (k,omega) grid per GPU, fp64 (BASELINE.json configs[3])",
-                       "nk": NK, "nw": NW, "interior_nodes": eq.n_nodes, "n_bisect": N_BISECT, "refine_rounds_9section": REFINE_ROUNDS,
+                       "nk": NK, "nw": NW, "interior_nodes": eq.n_nodes, "n_bisect": N_BISECT, "refine_rounds_9section": REFINE_ROUNDS, "refine_polish_steps": REFINE_POLISH,
                        "brackets_per_step": brackets_total, "roots_per_step": roots_total,
                        "gathered_root_records": gathered_rows,
                        "parallelism": f"m-tiled x{world}, one RCCL all-gather of the root table" if world > 1 else "single GPU"},

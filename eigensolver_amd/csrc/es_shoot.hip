@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
                                                            long cells, const double* __restrict__ D,
                                                            const uint64_t* __restrict__ masks,
                                                            const int* __restrict__ block_off, es_root_table tab,
-                                                           double* __restrict__ d_lo_sign) {
+                                                           double* __restrict__ d_lo_sign, double* __restrict__ d_hi_sign) {
   const long c = (long)blockIdx.x * 256 + threadIdx.x;
   if (c >= cells) return;
   const uint64_t m = masks[c >> 6];
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
   tab.d_w_lo[pos] = pick_w(wv, w_mode, k, (int)row, nw, j);
   tab.d_w_hi[pos] = pick_w(wv, w_mode, k, (int)row, nw, j + 1);
   d_lo_sign[pos] = D[c];
+  d_hi_sign[pos] = D[c + 1];
 }
 
 // Bracket refinement by 9-section: 8 lanes share one bracket (8 brackets per wave).  Per round the 8 lanes
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
 // the bracket at least as much as n_bisect bisections would; uniform trip count, no divergence.
 template <int FAM>
 __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
-                                                    int n, int n_rounds, double tol_percent) {
+                                                    const double* __restrict__ d_hi, int n, int n_rounds,
+                                                    int n_polish, double tol_percent) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 3, j = lane & 7;
   const int i = blockIdx.x * 8 + g;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
   double lo = in ? tab.d_w_lo[i] : 1.0;
   double hi = in ? tab.d_w_hi[i] : 2.0;
   double flo = in ? d_lo[i] : 1.0;
+  double fhi = in ? d_hi[i] : -1.0;
   const double frac = (double)(j + 1) / 9.0;
   double D, rel; uint8_t st;
   for (int it = 0; it < n_rounds; ++it) {
@@ -213,12 +216,21 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
     const int first = bits ? (__ffs((int)bits) - 1) : 8;         // first point whose sign differs from D(lo)
     const int src_hi = (g << 3) + (first < 8 ? first : 7);
     const int src_lo = (g << 3) + (first > 0 ? first - 1 : 0);
-    const double x_hi = __shfl(x, src_hi), x_lo = __shfl(x, src_lo), d_lo_new = __shfl(D, src_lo);
-    if (first < 8) hi = x_hi;
+    const double x_hi = __shfl(x, src_hi), d_hi_new = __shfl(D, src_hi);
+    const double x_lo = __shfl(x, src_lo), d_lo_new = __shfl(D, src_lo);
+    if (first < 8) { hi = x_hi; fhi = d_hi_new; }
     if (first > 0) { lo = x_lo; flo = (d_lo_new == d_lo_new) ? d_lo_new : flo; }
   }
-  const double root = lo + (hi - lo) * 0.5;
-  shoot_point<FAM>(P, k, root, root, D, rel, st);
+  // Newton-type polish in fp64: regula-falsi (secant through the bracket ends) steps, every lane of the group the same
+  double root = lo + (hi - lo) * 0.5;
+  if (n_polish == 0) shoot_point<FAM>(P, k, root, root, D, rel, st);
+  for (int it = 0; it < n_polish; ++it) {
+    double x = lo - flo * (hi - lo) / (fhi - flo);
+    if (!(x > lo && x < hi)) x = lo + (hi - lo) * 0.5;           // also catches NaN
+    shoot_point<FAM>(P, k, x, x, D, rel, st);
+    root = x;
+    if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }
+  }
   if (in && j == 0) {
     tab.d_w[i] = root;
     tab.d_w_lo[i] = lo;
@@ -276,13 +288,13 @@ int launch_points(es_context* ctx, const es_problem* prob, const double* d_k, co
 }
 
 template <int FAM>
-int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const double* d_lo, int n,
-                  int n_bisect, double tol) {
+int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const double* d_lo,
+                  const double* d_hi, int n, int n_bisect, double tol) {
   // 9-section rounds equivalent to n_bisect halvings: 9^R >= 2^n_bisect
   int rounds = 0;
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= 9.0) ++rounds;
-  hipLaunchKernelGGL((refine_kernel<FAM>), dim3((n + 7) / 8), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, n,
-                     rounds, tol);
+  hipLaunchKernelGGL((refine_kernel<FAM>), dim3((n + 7) / 8), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, d_hi,
+                     n, rounds, ES_REFINE_POLISH, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
@@ -482,11 +494,11 @@ extern "C" int es_shoot_find_roots(es_context* ctx, const es_problem* prob, cons
   *h_count = total;
   const int n = total < table->capacity ? total : table->capacity;
   if (n > 0) {
-    // the d_w column doubles as scratch for D at the lower bracket end until refinement overwrites it
+    // the d_w / d_resid columns double as scratch for D at the two bracket ends until refinement overwrites them
     hipLaunchKernelGGL(bracket_emit_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w, nw, w_mode, cells,
-                       d_D, ctx->d_masks, ctx->d_block_counts, *table, table->d_w);
+                       d_D, ctx->d_masks, ctx->d_block_counts, *table, table->d_w, table->d_resid);
     ES_HIP_CHECK(ctx, hipGetLastError());
-#define CALL_REF(F) launch_refine<F>(ctx, prob, *table, table->d_w, n, n_bisect, tol_percent)
+#define CALL_REF(F) launch_refine<F>(ctx, prob, *table, table->d_w, table->d_resid, n, n_bisect, tol_percent)
     int rr;
     switch (prob->dev.family) {
       case FAM_CYL0: rr = CALL_REF(FAM_CYL0); break;

@@ -11,6 +11,7 @@ struct es_problem {
 
 namespace es_shoot_shared {
 
+constexpr int ES_REFINE_POLISH = 2;   // regula-falsi steps after the 9-section rounds (0: report the bracket midpoint)
 constexpr int CH = 128;   // RK4 steps per LDS chunk: (2*CH+1) * NE * 8 B of LDS (12.3 KiB for NE = 6)
 
 template <int FAM>

@@ -171,8 +171,10 @@ typedef struct es_root_table {
  * (wavefront shuffle + ballot, ordered compaction: rows outer, omega inner); each bracket is narrowed at least
  * as far as `n_bisect` bisection steps would (the reference's 3-point linspace refinement, e.g. :823-829, run to
  * convergence; executed as ceil(n_bisect*ln2/ln9) rounds of 9-section, 8 lanes per bracket, always keeping the
- * sign change nearest to the lower end) and classified with the reference's acceptance rule rel < tol_percent.
- * The root reported is the midpoint of the final bracket.
+ * sign change nearest to the lower end), then polished in fp64 by two regula-falsi steps (the secant through the
+ * bracket ends: the Newton-type refinement of the north star, without a derivative of D) and classified with the
+ * reference's acceptance rule rel < tol_percent at the last secant point, which is the root reported;
+ * [w_lo, w_hi] is the final bracket around it.
  * d_D / d_status must hold the output of es_shoot_eval_grid for the same inputs. */
 int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                         const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,

@@ -443,6 +443,7 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
     }
   long n = count < capacity ? count : capacity;
   int rounds = 0;
+  const int polish = 2;
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= 9.0) ++rounds;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -451,7 +452,8 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
   for (long i = 0; i < n; ++i) {
     long c = cells[i], row = c / nw; int j = (int)(c - row * nw);
     double kk = k[row], lo = pick_w(w, w_mode, kk, row, nw, j), hi = pick_w(w, w_mode, kk, row, nw, j + 1);
-    double flo = D[c], d, r;
+    double flo = D[c], fhi = D[c + 1], d = NAN, r = NAN;
+    int s = ES_PT_NONFINITE;
     /* 9-section rounds, as the HIP refine_kernel: points lo + (hi-lo)*(j+1)/9, first sign change from the left */
     for (int it = 0; it < rounds; ++it) {
       double x[8], dv[8];
@@ -463,11 +465,19 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
       for (int j = 0; j < 8; ++j) if (dv[j] * flo < 0.0) { first = j; break; }
       double nlo = lo, nflo = flo;
       if (first > 0) { nlo = x[first - 1]; nflo = (dv[first - 1] == dv[first - 1]) ? dv[first - 1] : flo; }
-      if (first < 8) hi = x[first];
+      if (first < 8) { hi = x[first]; fhi = dv[first]; }
       lo = nlo; flo = nflo;
     }
+    /* regula-falsi polish (ES_REFINE_POLISH = 2 steps in the HIP kernel) */
     double root = lo + (hi - lo) * 0.5;
-    int s = port_eval(P, kk, root, &d, &r);
+    if (polish == 0) s = port_eval(P, kk, root, &d, &r);
+    for (int it = 0; it < polish; ++it) {
+      double x = lo - flo * (hi - lo) / (fhi - flo);
+      if (!(x > lo && x < hi)) x = lo + (hi - lo) * 0.5;
+      s = port_eval(P, kk, x, &d, &r);
+      root = x;
+      if (d * flo < 0.0) { hi = x; fhi = d; } else if (d == d) { lo = x; flo = d; }
+    }
     out_k[i] = kk; out_w[i] = root; out_lo[i] = lo; out_hi[i] = hi; out_resid[i] = r; out_row[i] = (int32_t)row;
     out_flag[i] = (s == ES_PT_OK && r < tol) ? 1 : 0;
   }
