@@ -216,3 +216,24 @@ def test_gpu_accepts_stored_reference_roots(es_ctx, tag):
         need = fmin[0] if mode == "sausage" else fmin[1]
         assert frac >= need, (tag, mode, frac, need)
         gp.close()
+
+
+@pytest.mark.parametrize("n_nodes", [2, 3, 130, 20001])
+def test_node_count_extremes(es_ctx, n_nodes):
+    """Node counts from the minimum (one RK4 step) to the reference's dense slab grids (SD-P:89 uses 1e5 nodes):
+    chunked LDS staging with ragged last chunks must agree with the CPU port."""
+    import dataclasses
+    from eigensolver_amd import ShootProblem, equilibrium as q
+    eq = dataclasses.replace(q.SlabDensity(width=1.5), n_nodes=n_nodes)
+    gp = ShootProblem(eq, "kink", ctx=es_ctx)
+    port = cases.port_problem(eq, "kink")
+    k = np.array([0.7, 1.9, 3.1])
+    W = np.linspace(1.01, 1.24, 70)
+    D, st, rel = gp.eval_grid(k, W, want_rel=True)
+    Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=8)
+    assert np.array_equal(st.cpu().numpy(), stp)
+    ok = stp == 0
+    assert ok.sum() > 50
+    sc = np.abs(Dp[ok]) * 100.0 / relp[ok]
+    assert (np.abs(D.cpu().numpy()[ok] - Dp[ok]) / sc).max() < 1e-11
+    gp.close()
