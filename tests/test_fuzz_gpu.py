@@ -1,0 +1,67 @@
+"""Seeded differential fuzz of the shooting kernels against the CPU port: random equilibria (all geometry families,
+azimuthal orders up to 10, both radial sign conventions, both far-field initial-value conventions, random node counts)
+and random (k, omega) points, including leaky / singular / continuum regions."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import cases  # noqa: E402
+
+
+def _random_case(rng):
+    from eigensolver_amd import equilibrium as q
+    fam = rng.integers(0, 5)
+    ic = [(1e-8, 1e-8), (1e-8, 1e-15)][rng.integers(0, 2)]
+    N = int(rng.integers(40, 700))
+    if fam == 0:
+        eq = q.CylinderFlow(U_i0=rng.uniform(-0.8, 0.9), width=rng.uniform(0.5, 3.0), c_e=rng.uniform(0.3, 1.6),
+                            vA_e=rng.uniform(0.4, 5.0), r_sign=rng.choice([-1.0, 1.0]), r_axis=rng.choice([1e-3, 1e-2]),
+                            n_nodes=N, ic=ic, L_factor=rng.choice([3.0, 7.0]))
+        mode, m = ("sausage", 0) if rng.random() < 0.3 else ("kink", int(rng.integers(1, 11)))
+    elif fam == 1:
+        eq = q.CylinderDensity(width=rng.uniform(0.6, 3.0), c_e=rng.uniform(0.3, 1.6), vA_e=rng.uniform(0.4, 5.0),
+                               r_sign=rng.choice([-1.0, 1.0]), n_nodes=N, ic=ic, c1_power=int(rng.choice([1, 2])))
+        mode, m = ("sausage", 0) if rng.random() < 0.3 else ("kink", int(rng.integers(1, 6)))
+    elif fam == 2:
+        eq = q.CylinderRotation(v_twist=rng.uniform(0.02, 0.3), power=rng.uniform(0.7, 1.4), r_axis=rng.choice([1e-3, 1e-2]),
+                                n_nodes=N, ic=ic)
+        mode, m = ("sausage", 0) if rng.random() < 0.3 else ("kink", int(rng.integers(1, 6)))
+    elif fam == 3:
+        eq = q.SlabDensity(width=rng.uniform(0.6, 4.0), n_nodes=N, ic=ic, L_factor=rng.choice([3.0, 7.0]),
+                           vA_i0=rng.uniform(1.0, 2.0), vA_e=rng.uniform(0.5, 3.0), c_e=rng.uniform(0.4, 1.4))
+        mode, m = rng.choice(["sausage", "kink"]), None
+    else:
+        eq = q.SlabFlow(U_i0=rng.uniform(-0.5, 0.9), U_e=rng.uniform(-0.2, 0.2), width=rng.uniform(0.6, 4.0), n_nodes=N,
+                        ic=ic, L_factor=rng.choice([3.0, 7.0]))
+        mode, m = rng.choice(["sausage", "kink"]), None
+    return eq, str(mode), m
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_grid_vs_port(es_ctx, seed):
+    from eigensolver_amd import ShootProblem
+    rng = np.random.default_rng(1000 + seed)
+    n_ok = 0
+    for _ in range(7):
+        eq, mode, m = _random_case(rng)
+        gp = ShootProblem(eq, mode, m, ctx=es_ctx)
+        port = cases.port_problem(eq, mode, m)
+        k = np.sort(rng.uniform(0.02, 4.5, 6))
+        vmax = 1.1 * max(eq.vA_e, eq.c_e, getattr(eq, "vA_i0", 1.0), 1.0)
+        W = np.sort(rng.uniform(0.05, vmax, 90))
+        D, st, rel = gp.eval_grid(k, W, want_rel=True)
+        D, st = D.cpu().numpy(), st.cpu().numpy()
+        Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=8)
+        # statuses agree except where a quantity sits within rounding of a threshold (none expected at random points)
+        assert np.mean(st == stp) > 0.995, (seed, type(eq).__name__, mode, m)
+        ok = (st == 0) & (stp == 0)
+        n_ok += int(ok.sum())
+        if ok.any():
+            sc = np.abs(Dp[ok]) * 100.0 / relp[ok]
+            err = np.abs(D[ok] - Dp[ok]) / sc
+            assert err.max() < 1e-10, (seed, type(eq).__name__, mode, m, err.max())
+        gp.close()
+    assert n_ok > 300
