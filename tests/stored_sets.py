@@ -1,35 +1,98 @@
-"""Known-answer sets: roots stored by the reference authors (`*/Example data/*.pickle`, converted without
-unpickling by tools/pickle_to_npz.py) with the parameter set each file was generated with.
-A stored root (k, omega) must satisfy the acceptance measure rel = 100|d|/max(|outer|,|inner|) < tol of its worker."""
+"""Known-answer sets: ALL 90 result files the reference authors stored (`*/Example data/*.pickle`, converted without
+unpickling by tools/pickle_to_npz.py; tag -> file in golden/stored_roots_index.json) with the parameter set each
+file was generated with.  The parameters are not stored in the files; they follow from the file names and the
+checked-in constants of the generating scripts:
+
+  width<NN>           dx / dr of the transition layer (09 -> 0.9, 125 -> 1.25, 1e5 -> uniform)
+  vtwist<VVV>_power<PP>   v_twist, power of the rotational-flow scripts
+  cylinder flow_06/_1/_1e5   width 0.6 / 1 / 1e5 with U_i0 = 0.05 (the checked-in script has U_i0 = 0.35; 0.05 is the
+                      only amplitude on a 0.05-spaced scan of [-1.2, 1.2] that the stored roots satisfy, at 96-100 %)
+
+A stored root (k, omega) must satisfy the acceptance measure rel = 100|d|/max(|outer|,|inner|) < tol of its worker
+(tol = the worker's own p_tol / xi_tol).  Pooled over a family the measures the port computes for the stored roots
+fill [0, tol) and stop sharply at tol (e.g. cylinder flow kink: 386 roots in [0.75, 1) tol, 1 in [1, 1.25) tol), which
+pins the oracle's measure to the reference's to about a percent (test_acceptance_measure_cutoff).  Exception: the
+rotational sausage_fast files, whose refined roots were accepted with the stale exterior constant of CR-SF:617 that a
+pointwise re-evaluation cannot know; their measures tail off smoothly above 1.5.  FLOORS (golden/stored_roots_floors.json, written by
+tools/stored_roots_survey.py) holds the minimum accepted fraction per file and mode; files listed in UNPINNED are
+carried as data but not asserted, with the reason."""
+import json
 import os
+import re
 
 import numpy as np
 
 from eigensolver_amd import equilibrium as q
 
-NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stored_roots.npz")
+HERE = os.path.dirname(os.path.abspath(__file__))
+NPZ = os.path.join(HERE, "golden", "stored_roots.npz")
+INDEX = json.load(open(os.path.join(HERE, "golden", "stored_roots_index.json")))
+_floors_path = os.path.join(HERE, "golden", "stored_roots_floors.json")
+FLOORS = json.load(open(_floors_path)) if os.path.exists(_floors_path) else {}
 
 PHOTO = dict(c_e=1.5, vA_e=0.5, r_sign=1.0, n_nodes=1000, ic=(1e-8, 1e-8))
-# tag -> (equilibrium, tolerance in percent to test with, minimum fraction (sausage, kink) that must pass)
-SETS = {
-    "slab_density_photospheric_w1e5": (q.SlabDensity(width=1e5, n_nodes=1001), 1.0, (0.97, 0.97)),
-    "slab_density_photospheric_w15": (q.SlabDensity(width=1.5, n_nodes=1001), 3.0, (0.55, 0.90)),   # 116/214 sausage roots lie in a continuum band
-    "slab_density_coronal_w1e5": (q.SlabDensity(width=1e5, vA_i0=1.2, vA_e=3.0, c_e=0.4, L_factor=3.0, n_nodes=1001), 1.0, (0.85, 0.88)),
-    "slab_flow_coronal_w1e5": (q.SlabFlow(U_i0=0.35, width=1e5), 1.0, (0.85, 0.85)),
-    "slab_flow_coronal_w15": (q.SlabFlow(U_i0=0.35, width=1.5), 1.0, (0.82, 0.85)),
-    "cyl_density_coronal_w1e5": (q.CylinderDensity(width=1e5), 1.0, (0.97, 0.97)),
-    "cyl_density_coronal_w09": (q.CylinderDensity(width=0.9), 1.0, (0.90, 0.85)),
-    "cyl_density_coronal_w15": (q.CylinderDensity(width=1.5), 1.0, (0.93, 0.93)),
-    "cyl_density_photospheric_w1e5": (q.CylinderDensity(width=1e5, **PHOTO), 3.0, (0.93, 0.97)),
-    "cyl_flow_coronal_noflow": (q.CylinderFlow(), 6.0, (0.97, 0.97)),
-    "cyl_rot_v01_p1_fund_kink": (q.CylinderRotation(v_twist=0.1, power=1.0), 3.0, (None, 0.95)),
-    "cyl_rot_v01_p08_sausage_fast": (q.CylinderRotation(v_twist=0.1, power=0.8, r_axis=0.01), 6.0, (0.93, None)),
+SLAB_CORONAL = dict(vA_i0=1.2, vA_e=3.0, c_e=0.4, L_factor=3.0)
+_WIDTH = {"06": 0.6, "09": 0.9, "1": 1.0, "125": 1.25, "15": 1.5, "175": 1.75, "3": 3.0, "5": 5.0, "1e5": 1e5}
+_VT = {"005": 0.05, "01": 0.1, "015": 0.15, "025": 0.25}
+_PW = {"08": 0.8, "09": 0.9, "1": 1.0, "125": 1.25}
+
+UNPINNED = {
+    "slab_density_coronal_w09_zoom": "zoom scan at k <= 1.5 whose every stored point lies inside the slow continuum of the "
+                                     "width-0.9 layer (sausage and kink arrays are the same 257 points)",
+    "slab_density_coronal_w15_zoom": "23-point zoom scan inside the slow continuum band; generating grid/tolerance unknown",
+    "slab_density_photospheric_w3_ZOOM": "zoom scan at k <= 0.75 hugging W = 0.8513 (a continuum edge); 30-40 % accepted",
+    "slab_flow_coronal_w125": "no (U_i0, width) on a 0.025 x {0.9,1,1.25,1.5,3,1e5} scan reproduces more than 21 % "
+                              "of the roots: generated with a profile the checked-in script no longer has",
 }
+
+
+def _width(tag):
+    m = re.search(r"_w(1e5|\d+)", tag)
+    return _WIDTH[m.group(1)]
+
+
+def describe(tag):
+    """(equilibrium, worker tolerance in percent) for a fixture tag."""
+    if tag.startswith("slab_density_photospheric"):
+        return q.SlabDensity(width=_width(tag), n_nodes=1001), 3.0                       # SD-P:275
+    if tag.startswith("slab_density_coronal"):
+        return q.SlabDensity(width=_width(tag), n_nodes=1001, **SLAB_CORONAL), 1.0       # SD-C:378
+    if tag.startswith("slab_flow_coronal"):
+        return q.SlabFlow(U_i0=0.35, width=_width(tag)), 1.0                             # SF-G:250
+    if tag.startswith("cyl_density_coronal"):
+        return q.CylinderDensity(width=_width(tag)), 1.0                                 # CD-C:522
+    if tag.startswith("cyl_density_photospheric"):
+        return q.CylinderDensity(width=_width(tag), **PHOTO), 3.0                        # CD-P:525 (xi_tol = 3)
+    if tag.startswith("cyl_flow_coronal"):
+        key = tag.rsplit("_", 1)[1]
+        if key == "noflow":
+            return q.CylinderFlow(), 6.0                                                 # CF:530
+        return q.CylinderFlow(U_i0=0.05, width=_WIDTH[key]), 6.0
+    if tag.startswith("cyl_rot"):
+        m = re.match(r"cyl_rot_v(\d+)_p(\d+)_(.*)", tag)
+        kind = m.group(3)
+        sausage = "sausage" in kind
+        # tolerances of the four rotational scripts: CR-KF:435 (2.5), CR-KS:441 (3), CR-SF:419 (1.5), CR-SS:423 (4.5)
+        # The slow-kink files were written with xi_tol = 5 (their acceptance measures fill [0, 5) and stop there: 2 of
+        # 1578 roots lie in [5, 6)), not with the checked-in 3.
+        tol = (4.5 if "slow" in kind else 1.5) if sausage else (5.0 if "slow" in kind else 2.5)
+        return q.CylinderRotation(v_twist=_VT[m.group(1)], power=_PW[m.group(2)], r_axis=0.01 if sausage else 0.001), tol
+    raise KeyError(tag)
 
 
 def pairs(tag):
     g = np.load(NPZ)
-    n = len([k for k in g.files if k.startswith(tag + "/")])
+    n = len(INDEX[tag]["sizes"])
     if n == 4:
         return [("sausage", g[tag + "/0"], g[tag + "/1"]), ("kink", g[tag + "/2"], g[tag + "/3"])]
     return [("kink" if "kink" in tag else "sausage", g[tag + "/0"], g[tag + "/1"])]
+
+
+def floor_of(tag, mode):
+    return FLOORS.get(tag, {}).get(mode)
+
+
+TAGS = sorted(INDEX)
+PINNED = [t for t in TAGS if t not in UNPINNED]
+# the historical interface: tag -> (equilibrium, tol, (min sausage fraction, min kink fraction))
+SETS = {t: (*describe(t), (floor_of(t, "sausage"), floor_of(t, "kink"))) for t in PINNED}

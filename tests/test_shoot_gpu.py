@@ -200,21 +200,30 @@ def test_full_size_properties(es_ctx):
     gp.close()
 
 
-@pytest.mark.parametrize("tag", ["cyl_flow_coronal_noflow", "cyl_density_coronal_w09", "cyl_rot_v01_p1_fund_kink",
-                                 "slab_flow_coronal_w15", "slab_density_coronal_w1e5"])
+def _stored_tags():
+    from tests import stored_sets as S
+    return S.PINNED
+
+
+@pytest.mark.parametrize("tag", _stored_tags())
 def test_gpu_accepts_stored_reference_roots(es_ctx, tag):
-    """Known answers: the roots the reference authors stored (Example data/*.pickle) satisfy the GPU determinant
-    at the tolerance of their worker."""
+    """Known answers: the roots the reference authors stored (all 86 pinned Example data/*.pickle files) satisfy the
+    GPU determinant at the tolerance of their worker, point for point as the CPU port decides."""
     from eigensolver_amd import ShootProblem
     from tests import stored_sets as S
-    eq, tol, fmin = S.SETS[tag]
+    eq, tol = S.describe(tag)
     for mode, w, k in S.pairs(tag):
+        if len(w) == 0:
+            continue
         gp = ShootProblem(eq, mode, ctx=es_ctx)
         D, st, rel = gp.eval_points(k, w, want_rel=True)
         rel = rel.cpu().numpy()
         frac = float(np.mean(rel < tol))
-        need = fmin[0] if mode == "sausage" else fmin[1]
-        assert frac >= need, (tag, mode, frac, need)
+        assert frac >= S.floor_of(tag, mode), (tag, mode, frac)
+        Dp, relp, stp = cases.port_problem(eq, mode).eval_points(k, w, nthreads=8)
+        assert np.array_equal(st.cpu().numpy(), stp)
+        decided = np.abs(relp - tol) > 1e-6 * tol                  # points not sitting on the threshold itself
+        assert np.array_equal((rel < tol)[decided], (relp < tol)[decided]), (tag, mode)
         gp.close()
 
 

@@ -2,7 +2,8 @@
 unpickling: the files are walked with pickletools.genops (a disassembler that executes nothing) and the float64
 payload of every numpy array is taken from its raw-bytes argument.
 
-    python tools/pickle_to_npz.py     ->  tests/golden/stored_roots.npz  (keys "<tag>/<i>")
+    python tools/pickle_to_npz.py     ->  tests/golden/stored_roots.npz  (keys "<tag>/<i>", all 90 pickles)
+                                          tests/golden/stored_roots_index.json  (tag -> reference file, array sizes)
 
 Layout of a reference pickle (Density_cylinder.py:1182-1183): a list of 4 float64 1-D arrays
 [omega_sausage, k_sausage, omega_kink, k_kink]; rotational files hold 2 arrays [omega, k].
@@ -16,20 +17,55 @@ import numpy as np
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "stored_roots.npz")
 
-FILES = {
-    "slab_density_photospheric_w1e5": "Slab/Non uniform density/Photospheric/Example data/width1e5.pickle",
-    "slab_density_photospheric_w15": "Slab/Non uniform density/Photospheric/Example data/width15.pickle",
-    "slab_density_coronal_w1e5": "Slab/Non uniform density/Coronal/Example data/width1e5_coronal.pickle",
-    "slab_flow_coronal_w1e5": "Slab/Non uniform flow/Example data/flow_width1e5_coronal.pickle",
-    "slab_flow_coronal_w15": "Slab/Non uniform flow/Example data/flow_width15_coronal.pickle",
-    "cyl_density_coronal_w1e5": "Cylinder/Non-uniform density/Coronal/Example data/Cylindrical_coronal_width1e5.pickle",
-    "cyl_density_coronal_w09": "Cylinder/Non-uniform density/Coronal/Example data/Cylindrical_coronal_width09.pickle",
-    "cyl_density_coronal_w15": "Cylinder/Non-uniform density/Coronal/Example data/Cylindrical_coronal_width15.pickle",
-    "cyl_density_photospheric_w1e5": "Cylinder/Non-uniform density/Photospheric/Example data/Cylindrical_photospheric_width_1e5.pickle",
-    "cyl_flow_coronal_noflow": "Cylinder/Non-uniform flow/Coronal/Example data/Cylindrical_coronal_flow_noflow.pickle",
-    "cyl_rot_v01_p1_fund_kink": "Cylinder/Rotational flow/Photospheric/Example data/Cylindrical_photospheric_vtwist01_power1_fund_kink.pickle",
-    "cyl_rot_v01_p08_sausage_fast": "Cylinder/Rotational flow/Photospheric/Example data/Cylindrical_photospheric_vtwist01_power08_sausage_fast.pickle",
+# tags of the first fixture set keep their historical names; every other pickle gets a tag derived from its path
+LEGACY_TAGS = {
+    "Slab/Non uniform density/Photospheric/Example data/width1e5.pickle": "slab_density_photospheric_w1e5",
+    "Slab/Non uniform density/Photospheric/Example data/width15.pickle": "slab_density_photospheric_w15",
+    "Slab/Non uniform density/Coronal/Example data/width1e5_coronal.pickle": "slab_density_coronal_w1e5",
+    "Slab/Non uniform flow/Example data/flow_width1e5_coronal.pickle": "slab_flow_coronal_w1e5",
+    "Slab/Non uniform flow/Example data/flow_width15_coronal.pickle": "slab_flow_coronal_w15",
+    "Cylinder/Non-uniform density/Coronal/Example data/Cylindrical_coronal_width1e5.pickle": "cyl_density_coronal_w1e5",
+    "Cylinder/Non-uniform density/Coronal/Example data/Cylindrical_coronal_width09.pickle": "cyl_density_coronal_w09",
+    "Cylinder/Non-uniform density/Coronal/Example data/Cylindrical_coronal_width15.pickle": "cyl_density_coronal_w15",
+    "Cylinder/Non-uniform density/Photospheric/Example data/Cylindrical_photospheric_width_1e5.pickle": "cyl_density_photospheric_w1e5",
+    "Cylinder/Non-uniform flow/Coronal/Example data/Cylindrical_coronal_flow_noflow.pickle": "cyl_flow_coronal_noflow",
+    "Cylinder/Rotational flow/Photospheric/Example data/Cylindrical_photospheric_vtwist01_power1_fund_kink.pickle": "cyl_rot_v01_p1_fund_kink",
+    "Cylinder/Rotational flow/Photospheric/Example data/Cylindrical_photospheric_vtwist01_power08_sausage_fast.pickle": "cyl_rot_v01_p08_sausage_fast",
 }
+FAMILY_PREFIX = [
+    ("Slab/Non uniform density/Photospheric", "slab_density_photospheric"),
+    ("Slab/Non uniform density/Coronal", "slab_density_coronal"),
+    ("Slab/Non uniform flow", "slab_flow_coronal"),
+    ("Cylinder/Non-uniform density/Coronal", "cyl_density_coronal"),
+    ("Cylinder/Non-uniform density/Photospheric", "cyl_density_photospheric"),
+    ("Cylinder/Non-uniform flow/Coronal", "cyl_flow_coronal"),
+    ("Cylinder/Rotational flow/Photospheric", "cyl_rot"),
+]
+
+
+def tag_of(rel):
+    """Stable fixture tag of a reference pickle (path relative to the reference root)."""
+    if rel in LEGACY_TAGS:
+        return LEGACY_TAGS[rel]
+    fam = next(pre for path, pre in FAMILY_PREFIX if rel.startswith(path))
+    stem = os.path.splitext(os.path.basename(rel))[0]
+    for junk in ("Cylindrical_photospheric_", "Cylindrical_coronal_", "_coronal", "flow_"):
+        stem = stem.replace(junk, "")
+    stem = stem.replace("width_", "w").replace("width", "w").replace("vtwist", "v").replace("power", "p")
+    return f"{fam}_{stem}"
+
+
+def all_files():
+    out = {}
+    for root, _, names in os.walk(REF):
+        for n in sorted(names):
+            if n.endswith(".pickle"):
+                rel = os.path.relpath(os.path.join(root, n), REF)
+                t = tag_of(rel)
+                assert t not in out, (t, rel, out[t])
+                out[t] = rel
+    return dict(sorted(out.items()))
+
 
 ALLOWED_GLOBALS = {("numpy.core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
                    ("numpy._core.multiarray", "_reconstruct")}
@@ -69,17 +105,20 @@ def arrays_from_pickle(path):
 
 
 def main():
-    res = {}
-    for tag, rel in FILES.items():
+    import json
+    res, index = {}, {}
+    for tag, rel in all_files().items():
         arrs = arrays_from_pickle(os.path.join(REF, rel))
-        # drop the tiny 'b' dtype-description strings that are not multiples of 8 (already filtered) and keep data
-        arrs = [a for a in arrs if np.all(np.isfinite(a))]
+        assert all(np.all(np.isfinite(a)) for a in arrs), tag
         assert len(arrs) in (2, 4), (tag, len(arrs), [a.shape for a in arrs])
         for i, a in enumerate(arrs):
             res[f"{tag}/{i}"] = a
+        index[tag] = {"file": rel, "sizes": [int(a.size) for a in arrs]}
         print(tag, [a.shape for a in arrs])
     np.savez_compressed(OUT, **res)
-    print("wrote", OUT)
+    with open(OUT.replace(".npz", "_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+    print("wrote", OUT, len(index), "files")
 
 
 if __name__ == "__main__":
