@@ -23,7 +23,7 @@ namespace {
 using namespace es_shoot_shared;
 
 // ------------------------------------------------------------------------------------------------------------
-template <int FAM, int PTS, int MAXT>
+template <int FAM, int PTS, int MAXT, bool TRACK>
 __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
                                                           const double* __restrict__ wv, int nw, int w_mode,
                                                           double* __restrict__ Dout, double* __restrict__ relout,
@@ -31,6 +31,8 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr bool DIAG = FamTraits<FAM>::DIAG;
   constexpr int LSTRIDE = 2 * CH + 1;
+  // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
+  constexpr bool PAIR = (FAM == FAM_CYL0) && (PTS == 4) && !TRACK;
   __shared__ double lds[NE * LSTRIDE];
   const int T = blockDim.x;
   const int nsteps = P.n_nodes - 1;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
     const KScal s = make_kscal(P, k);
     for (int w0 = 0; w0 < nw; w0 += T * PTS) {
       double w[PTS], zp[PTS], zq[PTS];
-      Coef B0[PTS];
+      Coef B0[PTS], B1[PTS];
       SignTrack trk[PTS];
       bool inr[PTS];
 #pragma unroll
@@ -75,25 +77,46 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
           for (int f = 0; f < NE; ++f) eL[f] = lds[f * LSTRIDE + 2 * nst];
 #pragma unroll
           for (int p = 0; p < PTS; ++p) {
-            coefficients<FAM>(eL, P, s, w[p], B0[p], trk[p]);
+            coefficients<FAM, TRACK>(eL, P, s, w[p], B0[p], trk[p]);
             adjoint_start(P, B0[p], zp[p], zq[p]);
           }
         }
-        for (int j = nst - 1; j >= 0; --j) {
-          double em[NE], e1[NE];
+        // one RK4 step of all PTS points: coefficients of node 2j+1 / 2j from LDS (broadcast reads), start
+        // coefficients BIN, end coefficients written to BOUT (the next step's start)
+#define ES_MARCH_STEP(J, BIN, BOUT)                                                         \
+        {                                                                                   \
+          double em[NE], e1[NE];                                                            \
+          _Pragma("unroll") for (int f = 0; f < NE; ++f) {                                  \
+            em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                         \
+            e1[f] = lds[f * LSTRIDE + 2 * (J)];                                             \
+          }                                                                                 \
+          _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                 \
+            Coef Bm;                                                                        \
+            coefficients2<FAM, TRACK>(em, e1, P, s, w[p], Bm, BOUT[p], trk[p]);             \
+            rk4_step_adjoint<DIAG>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);       \
+          }                                                                                 \
+        }
+        int j = nst - 1;
+        if (PAIR) {
+          // steps in pairs with the roles of B0 / B1 swapped, so that no coefficient is copied between iterations
+          if (nst & 1) {
+            ES_MARCH_STEP(j, B0, B1)
 #pragma unroll
-          for (int f = 0; f < NE; ++f) {
-            em[f] = lds[f * LSTRIDE + 2 * j + 1];
-            e1[f] = lds[f * LSTRIDE + 2 * j];
+            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+            --j;
           }
+          for (; j >= 1; j -= 2) {
+            ES_MARCH_STEP(j, B0, B1)
+            ES_MARCH_STEP(j - 1, B1, B0)
+          }
+        } else {
+          for (; j >= 0; --j) {
+            ES_MARCH_STEP(j, B0, B1)
 #pragma unroll
-          for (int p = 0; p < PTS; ++p) {
-            Coef Bm, B1;
-            coefficients2<FAM>(em, e1, P, s, w[p], Bm, B1, trk[p]);
-            rk4_step_adjoint<DIAG>(zp[p], zq[p], B0[p], Bm, B1, h, h2, h6, h3);
-            B0[p] = B1;
+            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
           }
         }
+#undef ES_MARCH_STEP
       }
       // boundary: exterior closed form + far-end condition + mismatch
       double bf[FamTraits<FAM>::NB], ef[NE];
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
         const int iw = w0 + p * T + (int)threadIdx.x;
         const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X[p], zp[p], zq[p], ef);
         double D, rel; uint8_t st;
-        finish_point(P, M, X[p], trk[p].crossed(), D, rel, st);
+        finish_point(P, M, X[p], TRACK ? trk[p].crossed() : band_crossed(P, k, w[p]), D, rel, st);
         const size_t o = (size_t)row * nw + iw;
         Dout[o] = D;
         stout[o] = st;
@@ -264,16 +287,28 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
     if (T > maxT) T = maxT;
     return T;
   };
+  // FAM_CYL0 with connected continuum bands: no per-node sign tracking (band_crossed)
+  const bool bands = (FAM == FAM_CYL0) && prob->dev.use_bands;
+#define ES_LAUNCH_GRID(PTS, MAXT, T)                                                                                \
+  do {                                                                                                              \
+    if (FAM == FAM_CYL0 && bands)                                                                                   \
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, FAM != FAM_CYL0>), dim3(grid), dim3(T), 0, ctx->stream, \
+                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                \
+    else                                                                                                            \
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, true>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, \
+                         d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                           \
+  } while (0)
   if (variant == 1) {
     const int T = roundT((nw + 3) / 4, 512);
-    hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 512>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);
+    ES_LAUNCH_GRID(4, 512, T);
   } else if (variant == 0) {
     const int T = roundT((nw + 1) / 2, 1024);
-    hipLaunchKernelGGL((shoot_grid_kernel<FAM, 2, 1024>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);
+    ES_LAUNCH_GRID(2, 1024, T);
   } else {
     const int T = roundT(nw, 1024);
-    hipLaunchKernelGGL((shoot_grid_kernel<FAM, 1, 1024>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);
+    ES_LAUNCH_GRID(1, 1024, T);
   }
+#undef ES_LAUNCH_GRID
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
@@ -408,6 +443,24 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
   S.cT2_i = (S.S_i > 0.0) ? S.c2_i * S.vA2_i / S.S_i : 0.0;
   S.rho_i = d->rho_i;
   S.accept_norm = d->accept_norm;
+  if (d->geometry == ES_GEOM_CYLINDER) {
+    // continuum bands in phase speed (band_crossed): node intervals |W - vz| < |bA| (Alfven), < |bA| sqrt(q) (cusp)
+    S.use_bands = 1;
+    for (int t = 0; t < 2; ++t) {
+      double lo_min = INFINITY, lo_max = -INFINITY, hi_min = INFINITY, hi_max = -INFINITY, lo_prev = 0.0, hi_prev = 0.0;
+      for (int i = 0; i < npts; ++i) {
+        const double a = fabs(B(C0_BA, i)) * (t == 0 ? 1.0 : sqrt(B(C0_Q, i)));
+        const double lo = B(C0_VZ, i) - a, hi = B(C0_VZ, i) + a;
+        if (!(a > 0.0) || !std::isfinite(a)) S.use_bands = 0;                       // empty interval: no union
+        if (i > 0 && !(lo < hi_prev && lo_prev < hi)) S.use_bands = 0;             // consecutive intervals disjoint
+        lo_min = fmin(lo_min, lo); lo_max = fmax(lo_max, lo);
+        hi_min = fmin(hi_min, hi); hi_max = fmax(hi_max, hi);
+        lo_prev = lo; hi_prev = hi;
+      }
+      S.band[t][0] = lo_min; S.band[t][1] = lo_max; S.band[t][2] = hi_min; S.band[t][3] = hi_max;
+    }
+    if (getenv("ES_FORCE_SIGN_TRACKING")) S.use_bands = 0;
+  }
   if (hipSetDevice(ctx->device) != hipSuccess ||
       hipMalloc(&p->d_base, base.size() * sizeof(double)) != hipSuccess) {
     ctx->last_error = "hipMalloc(base table) failed";

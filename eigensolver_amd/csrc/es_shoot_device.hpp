@@ -44,10 +44,13 @@ struct ShootDev {
   double slab_sign;   // -1 sausage: Vx(+1) = -Vx(-1);  +1 kink
   double c2_i, vA2_i, S_i, cT2_i, rho_i;   // uniform interior speeds of the flow slab
   int accept_norm;    // 0: rel uses max(|outer|,|inner|); 1: |outer| only (CR-KS:722)
+  // FAM_CYL0: continuum bands in phase speed, [term][min lo, max lo, min hi, max hi] (term 0 Alfven, 1 cusp)
+  int use_bands;
+  double band[2][4];
 };
 
 template <int FAM> struct FamTraits;
-template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 6; static constexpr bool DIAG = false; };
+template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 7; static constexpr bool DIAG = false; };
 template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 11, NE = 16; static constexpr bool DIAG = true; };
 template <> struct FamTraits<FAM_SLABD> { static constexpr int NB = 3, NE = 5; static constexpr bool DIAG = false; };
 template <> struct FamTraits<FAM_SLABF> { static constexpr int NB = 3, NE = 3; static constexpr bool DIAG = true; };
@@ -84,8 +87,13 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
     e[1] = wA2;                                // omega_A^2
     e[2] = wA2 * b[C0_Q];                      // omega_c^2 = omega_A^2 c^2/(c^2+vA^2)
     e[3] = b[C0_A1];                           // rho / r
-    e[4] = b[C0_B1];                           // r / (rho S)
-    e[5] = s.m2 * b[C0_E1] + s.k2 * b[C0_E2];  // (m^2/r^2 + k^2) r / rho
+    // -r C2/(rho S) = g t2 - B (t2 + omega_c^2)^2 with t2 = Om^2 - omega_c^2, B = r/(rho S),
+    // g = (m^2/r^2 + k^2) r/rho:  Horner coefficients in t2
+    const double Bq = b[C0_B1];
+    const double g = s.m2 * b[C0_E1] + s.k2 * b[C0_E2];
+    e[4] = -Bq;
+    e[5] = g - 2.0 * (Bq * e[2]);
+    e[6] = -(Bq * (e[2] * e[2]));
   } else if (FAM == FAM_CYLT) {
     const double r = b[CT_R], invr = b[CT_INVR], rho = b[CT_RHO], S = b[CT_S];
     const double Bphi = b[CT_BPHR] * r, vphi = b[CT_VPHR] * r;
@@ -126,8 +134,9 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
 }
 
 // sign tracking for the continuum / singular-point flag: the IEEE sign bits (high dwords) of every watched term are
-// OR-ed and AND-ed over all nodes with 32-bit integer ops (cheaper than fp64 compares in the hot loop); a term
-// whose OR has the sign bit set while its AND has not took both signs, i.e. crossed zero inside the domain.
+// OR-ed and AND-ed over all nodes with 32-bit integer ops (0.6 of the issue cost of an fp64 op on gfx950, and cheaper
+// than v_cmp_lt_f64 + scalar mask accumulation, which was measured: tools/probe/valu_probe.hip); a term whose OR
+// has the sign bit set while its AND has not took both signs, i.e. crossed zero inside the domain.
 struct SignTrack {
   int any_or[4] = {0, 0, 0, 0};
   int any_and[4] = {-1, -1, -1, -1};
@@ -143,31 +152,48 @@ struct SignTrack {
   }
 };
 
+// FAM_CYL0 without per-node tracking (ShootDev::use_bands): omega_A^2 = k^2 bA^2 and the Doppler shift k v_z scale
+// with k, so  t1_j < 0  <=>  |W - vz_j| < |bA_j|  with W = omega/k, an interval (lo_j, hi_j) that does not depend on
+// k.  When consecutive intervals overlap (checked on the host at problem creation) their union is
+// (min lo, max hi) and  "negative at some node but not at all nodes"  <=>  W in (min lo, max hi) and not
+// (max lo < W < min hi): four comparisons per point instead of four integer ops per node.  Same for the cusp term
+// with |bA_j| sqrt(q_j).
+__device__ __forceinline__ bool band_crossed(const ShootDev& P, double k, double w) {
+  const double W = w / k;
+  bool c = false;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bool some = (W > P.band[t][0]) && (W < P.band[t][3]);
+    const bool all = (W > P.band[t][1]) && (W < P.band[t][2]);
+    c = c || (some && !all);
+  }
+  return c;
+}
+
 // Coefficient matrix A(x; k, omega) of one node in two parts: everything except ONE reciprocal.  The entries marked
 // "/den" are numerators; coef_finish() multiplies them with 1/den.  The caller computes the reciprocals of the
 // mid-point and end-point denominators of a step with a single IEEE division: inv = 1/(den_m * den_1),
 // 1/den_m = den_1 * inv, 1/den_1 = den_m * inv  (one v_div sequence per RK4 step instead of two).
 struct CoefPre { double n11, n12, n21, n22, den; };
 
-template <int FAM>
+template <int FAM, bool TRACK = true>
 __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, const KScal& s, double w, CoefPre& C,
                                          SignTrack& st) {
   if (FAM == FAM_CYL0) {
     const double Om = w - e[0];
-    const double Om2 = Om * Om;
-    const double t1 = Om2 - e[1];
-    const double t2 = Om2 - e[2];
-    st.add(0, t1); st.add(1, t2);
+    const double t1 = fma(Om, Om, -e[1]);                // Om^2 - omega_A^2
+    const double t2 = fma(Om, Om, -e[2]);                // Om^2 - omega_c^2
+    if (TRACK) { st.add(0, t1); st.add(1, t2); }
     C.n11 = 0.0; C.n22 = 0.0;
     C.n12 = e[3] * t1;                                   // rho (Om^2 - wA^2) / r
-    C.n21 = fma(e[5], t2, -(e[4] * (Om2 * Om2)));        // -r C2 / (rho S)            /den
+    C.n21 = fma(fma(e[4], t2, e[5]), t2, e[6]);          // -r C2 / (rho S)            /den
     C.den = t1 * t2;
   } else if (FAM == FAM_CYLT) {
     const double Om = w - e[0];
     const double Om2 = Om * Om;
     const double t1 = Om2 - e[1];
     const double t2 = Om2 - e[2];
-    st.add(0, t1); st.add(1, t2);
+    if (TRACK) { st.add(0, t1); st.add(1, t2); }
     const double D = e[3] * t1 * t2;
     const double Q = Om2 * e[6] - t1 * e[5] + Om * e[7];
     const double T = e[8] + e[9] * Om;
@@ -175,7 +201,7 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     const double C1 = Q * OmP - e[10] * t2 * T;
     const double C2 = Om2 * Om2 - e[11] * t2;
     const double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
-    st.add(2, C3 * D);                                   // F = r D / C3 changes sign where C3 does
+    if (TRACK) { st.add(2, C3 * D); }   // F = r D / C3 changes sign where C3 does
     C.n11 = -C1;                                         // all four entries /den
     C.n22 = C1;
     C.n12 = C3 * e[15];
@@ -186,7 +212,7 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     const double n1 = e[0] - w2;                         // k^2 c^2 - w^2
     const double n2 = e[1] - w2;                         // k^2 cT^2 - w^2
     const double n3 = e[2] - w2;                         // k^2 vA^2 - w^2
-    st.add(0, n1); st.add(1, n2); st.add(2, n3);
+    if (TRACK) { st.add(0, n1); st.add(1, n2); st.add(2, n3); }
     C.n11 = 0.0; C.n22 = 0.0;
     C.n12 = n1;                                          // 1/F = n1 / (rho S n2)      /den
     C.n21 = e[4] * n3;                                   // F m0
@@ -197,7 +223,7 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     const double t = Om2 - s.kcT2;
     const double n1 = s.kc2 - Om2;
     const double n3 = s.kvA2 - Om2;
-    st.add(0, n1); st.add(1, t); st.add(2, n3); st.add(3, Om);
+    if (TRACK) { st.add(0, n1); st.add(1, t); st.add(2, n3); st.add(3, Om); }
     const double m0 = (n1 * n3) / (P.S_i * (s.kcT2 - Om2));                              // SF-G:416
     const double Dref = 2.0 * e[1] * (t + s.k4c / (P.S_i * t)) / (Om * (Om2 - s.kc2));   // SF-G:421
     const double coeff = e[2] / Om + e[1] * Dref / Om - m0;                              // SF-G:427
@@ -223,11 +249,11 @@ __device__ __forceinline__ void coef_finish(const CoefPre& C, double inv, Coef& 
 }
 
 // single node (first node of a traversal): its own division
-template <int FAM>
+template <int FAM, bool TRACK = true>
 __device__ __forceinline__ void coefficients(const double* e, const ShootDev& P, const KScal& s, double w,
                                              Coef& A, SignTrack& st) {
   CoefPre C;
-  coef_pre<FAM>(e, P, s, w, C, st);
+  coef_pre<FAM, TRACK>(e, P, s, w, C, st);
   coef_finish<FAM>(C, 1.0 / C.den, A);
 }
 
@@ -248,12 +274,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 
 // two nodes of one RK4 step (mid-point, end-point) with one division
-template <int FAM>
+template <int FAM, bool TRACK = true>
 __device__ __forceinline__ void coefficients2(const double* em, const double* e1, const ShootDev& P,
                                               const KScal& s, double w, Coef& Am, Coef& A1, SignTrack& st) {
   CoefPre Cm, C1;
-  coef_pre<FAM>(em, P, s, w, Cm, st);
-  coef_pre<FAM>(e1, P, s, w, C1, st);
+  coef_pre<FAM, TRACK>(em, P, s, w, Cm, st);
+  coef_pre<FAM, TRACK>(e1, P, s, w, C1, st);
   const double inv = fast_rcp(Cm.den * C1.den);
   coef_finish<FAM>(Cm, C1.den * inv, Am);
   coef_finish<FAM>(C1, Cm.den * inv, A1);

@@ -57,9 +57,9 @@ __device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& 
 }
 
 // One (k, omega) pair per lane.  Base-table indices are wave-uniform -> scalar loads.
-template <int FAM>
-__device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
-                                            double& rel, uint8_t& st) {
+template <int FAM, bool TRACK>
+__device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, double w, double w_cst, double& D,
+                                                 double& rel, uint8_t& st) {
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr int NB = FamTraits<FAM>::NB;
   constexpr bool DIAG = FamTraits<FAM>::DIAG;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
   load_base<FAM>(P, 2 * nsteps, b);
   make_entry<FAM>(b, s, e);
   Coef B0;
-  coefficients<FAM>(e, P, s, w, B0, trk);
+  coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
   double zp, zq;
   adjoint_start(P, B0, zp, zq);
   for (int j = nsteps - 1; j >= 0; --j) {
@@ -82,12 +82,19 @@ __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double 
     make_entry<FAM>(b, s, e);
     load_base<FAM>(P, 2 * j, b);
     make_entry<FAM>(b, s, e2);
-    coefficients2<FAM>(e, e2, P, s, w, Bm, B1, trk);
+    coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
     rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
     B0 = B1;
   }
   const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
-  finish_point(P, M, X, trk.crossed(), D, rel, st);
+  finish_point(P, M, X, TRACK ? trk.crossed() : band_crossed(P, k, w), D, rel, st);
+}
+
+template <int FAM>
+__device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
+                                            double& rel, uint8_t& st) {
+  if (FAM == FAM_CYL0 && P.use_bands) shoot_point_impl<FAM, FAM != FAM_CYL0>(P, k, w, w_cst, D, rel, st);   // wave-uniform branch
+  else shoot_point_impl<FAM, true>(P, k, w, w_cst, D, rel, st);
 }
 
 }  // namespace es_shoot_shared

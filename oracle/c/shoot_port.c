@@ -102,6 +102,8 @@ typedef struct {
   int m, m_ext, axis_bc, c1_power;
   double bc_const, slab_sign, c2_i, vA2_i, S_i, cT2_i, rho_i;
   int accept_norm;
+  int use_bands;          /* family 0: continuum flag from phase-speed bands instead of per-node sign tracking */
+  double band[2][4];      /* [Alfven, cusp][min lo, max lo, min hi, max hi] */
 } port_problem;
 
 static const int NB_OF[4] = {7, 11, 3, 3};
@@ -143,22 +145,50 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
   P->cT2_i = (P->S_i > 0.0) ? P->c2_i * P->vA2_i / P->S_i : 0.0;
   P->rho_i = d->rho_i;
   P->accept_norm = d->accept_norm;
+  if (d->geometry == ES_GEOM_CYLINDER) {
+    /* node j is inside the Alfven (cusp) continuum of phase speed W iff |W - vz_j| < |bA_j| (|bA_j| sqrt(q_j)); if
+       consecutive node intervals overlap, "inside at some node but not at all" is a test against four numbers */
+    P->use_bands = getenv("ES_FORCE_SIGN_TRACKING") ? 0 : 1;
+    for (int t = 0; t < 2; ++t) {
+      double lo_min = INFINITY, lo_max = -INFINITY, hi_min = INFINITY, hi_max = -INFINITY, lo_prev = 0.0, hi_prev = 0.0;
+      for (int i = 0; i < npts; ++i) {
+        double a = fabs(P->base[(size_t)1 * npts + i]);
+        if (t == 1) a *= sqrt(P->base[(size_t)2 * npts + i]);
+        double vz = P->base[i], lo = vz - a, hi = vz + a;
+        if (!(a > 0.0) || !isfinite(a)) P->use_bands = 0;
+        if (i > 0 && !(lo < hi_prev && lo_prev < hi)) P->use_bands = 0;
+        lo_min = fmin(lo_min, lo); lo_max = fmax(lo_max, lo); hi_min = fmin(hi_min, hi); hi_max = fmax(hi_max, hi);
+        lo_prev = lo; hi_prev = hi;
+      }
+      P->band[t][0] = lo_min; P->band[t][1] = lo_max; P->band[t][2] = hi_min; P->band[t][3] = hi_max;
+    }
+  }
   return P;
+}
+static int band_crossed(const port_problem* P, double k, double w) {
+  const double W = w / k;
+  int c = 0;
+  for (int t = 0; t < 2; ++t) {
+    const int some = (W > P->band[t][0]) && (W < P->band[t][3]);
+    const int all = (W > P->band[t][1]) && (W < P->band[t][2]);
+    c |= (some && !all);
+  }
+  return c;
 }
 void port_destroy(port_problem* P) { if (P) { free(P->base); free(P); } }
 
 typedef struct { double k, k2, m, m2, kc2, kvA2, kcT2, k4c; } kscal;
 typedef struct { double a11, a12, a21, a22; } coef;
-/* IEEE sign bits of the watched terms OR-ed / AND-ed over all nodes (same bookkeeping as the HIP SignTrack) */
-typedef struct { int32_t any_or[4], any_and[4]; } strack;
+/* per watched term: "negative at some node" / "negative at every node" (same bookkeeping as the HIP SignTrack,
+   which keeps the two flags of all 64 lanes of a wave in scalar lane masks) */
+typedef struct { int some_neg[4], all_neg[4]; } strack;
 static inline void st_add(strack* s, int i, double t) {
-  uint64_t u; memcpy(&u, &t, 8);
-  int32_t hi = (int32_t)(u >> 32);
-  s->any_or[i] |= hi; s->any_and[i] &= hi;
+  const int neg = t < 0.0;
+  s->some_neg[i] |= neg; s->all_neg[i] &= neg;
 }
 static inline int st_crossed(const strack* s) {
-  return (((s->any_or[0] & ~s->any_and[0]) | (s->any_or[1] & ~s->any_and[1]) | (s->any_or[2] & ~s->any_and[2]) |
-           (s->any_or[3] & ~s->any_and[3])) < 0);
+  return ((s->some_neg[0] & ~s->all_neg[0]) | (s->some_neg[1] & ~s->all_neg[1]) | (s->some_neg[2] & ~s->all_neg[2]) |
+          (s->some_neg[3] & ~s->all_neg[3])) & 1;
 }
 
 static void make_entry(const port_problem* P, int pt, const kscal* s, double* e) {
@@ -167,8 +197,10 @@ static void make_entry(const port_problem* P, int pt, const kscal* s, double* e)
   switch (P->family) {
     case 0: {
       double wA = s->k * b[1], wA2 = wA * wA;
-      e[0] = s->k * b[0]; e[1] = wA2; e[2] = wA2 * b[2]; e[3] = b[3]; e[4] = b[4];
-      e[5] = s->m2 * b[5] + s->k2 * b[6];
+      double g = s->m2 * b[5] + s->k2 * b[6];
+      e[0] = s->k * b[0]; e[1] = wA2; e[2] = wA2 * b[2]; e[3] = b[3];
+      /* -r C2/(rho S) = g t2 - B (t2 + wc^2)^2, t2 = Om^2 - wc^2: Horner coefficients in t2 */
+      e[4] = -b[4]; e[5] = g - 2.0 * (b[4] * e[2]); e[6] = -(b[4] * (e[2] * e[2]));
     } break;
     case 1: {
       double r = b[0], invr = b[1], rho = b[2], S = b[3];
@@ -195,11 +227,11 @@ typedef struct { double n11, n12, n21, n22, den; } coefpre;
 static void coef_pre(const port_problem* P, const double* e, const kscal* s, double w, coefpre* C, strack* st) {
   switch (P->family) {
     case 0: {
-      double Om = w - e[0], Om2 = Om * Om, t1 = Om2 - e[1], t2 = Om2 - e[2];
-      st_add(st, 0, t1); st_add(st, 1, t2);
+      double Om = w - e[0], t1 = fma(Om, Om, -e[1]), t2 = fma(Om, Om, -e[2]);
+      if (st) { st_add(st, 0, t1); st_add(st, 1, t2); }
       C->n11 = 0.0; C->n22 = 0.0;
       C->n12 = e[3] * t1;
-      C->n21 = fma(e[5], t2, -(e[4] * (Om2 * Om2)));
+      C->n21 = fma(fma(e[4], t2, e[5]), t2, e[6]);
       C->den = t1 * t2;
     } break;
     case 1: {
@@ -351,12 +383,13 @@ int port_eval2(const port_problem* P, double k, double w, double w_cst, double* 
   coef B0, Bm, B1;
   /* adjoint march: one row of the transfer matrix, from the last node back to the boundary */
   make_entry(P, 2 * nsteps, &s, e);
-  coefficients(P, e, &s, w, &B0, &trk);
+  strack* tp = (P->family == 0 && P->use_bands) ? NULL : &trk;
+  coefficients(P, e, &s, w, &B0, tp);
   if (P->family <= 1 && P->axis_bc == ES_AXIS_SAUSAGE) { zp = B0.a11; zq = B0.a12; } else { zp = 1.0; zq = 0.0; }
   for (int j = nsteps - 1; j >= 0; --j) {
     make_entry(P, 2 * j + 1, &s, e);
     make_entry(P, 2 * j, &s, e2);
-    coefficients2(P, e, e2, &s, w, &Bm, &B1, &trk);
+    coefficients2(P, e, e2, &s, w, &Bm, &B1, tp);
     rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
     B0 = B1;
   }
@@ -387,7 +420,7 @@ int port_eval2(const port_problem* P, double k, double w, double w_cst, double* 
   *rel = fabs(d) * 100.0 / sc;
   if (X.status != ES_PT_OK) { *D = NAN; *rel = NAN; return st; }
   if (!isfinite(d)) return ES_PT_NONFINITE;
-  if (st_crossed(&trk)) st = ES_PT_CONTINUUM;
+  if (tp ? st_crossed(&trk) : band_crossed(P, k, w)) st = ES_PT_CONTINUUM;
   return st;
 }
 

@@ -33,3 +33,23 @@ def test_port_vs_truth(name):
         tol = 3e-8 * max(1.0, (1000.0 / eq.n_nodes) ** 4)
         assert abs(D[i] - d) <= tol * scale, (name, kk[i], ww[i], D[i], d)
     assert n_ok >= 4, (name, n_ok, n_cont)
+
+
+def test_continuum_bands_equal_per_node_tracking(monkeypatch):
+    """FAM_CYL0: the phase-speed band test (four comparisons per point) flags exactly the points the per-node sign
+    tracking flags, and leaves D untouched."""
+    from eigensolver_amd import equilibrium as q
+    photo = dict(c_e=1.5, vA_e=0.5, r_sign=1.0, n_nodes=1000, ic=(1e-8, 1e-8))
+    k = np.linspace(0.05, 4.0, 24)
+    W = np.linspace(0.3, 5.0, 400)
+    n_cont = 0
+    for eq, mode in [(q.CylinderFlow(U_i0=0.7, width=0.9), "kink"), (q.CylinderDensity(width=0.9), "sausage"),
+                     (q.CylinderDensity(width=1.5, **photo), "kink"), (q.CylinderFlow(U_i0=-0.35, width=3.0), "sausage")]:
+        monkeypatch.delenv("ES_FORCE_SIGN_TRACKING", raising=False)
+        Db, relb, stb = cases.port_problem(eq, mode).eval_grid(k, W, w_mode=1, nthreads=8)
+        monkeypatch.setenv("ES_FORCE_SIGN_TRACKING", "1")
+        Dt, relt, stt = cases.port_problem(eq, mode).eval_grid(k, W, w_mode=1, nthreads=8)
+        assert np.array_equal(stb, stt)
+        assert np.array_equal(Db[stb == 0], Dt[stt == 0])
+        n_cont += int((stb == 3).sum())
+    assert n_cont > 1000

@@ -246,3 +246,29 @@ def test_node_count_extremes(es_ctx, n_nodes):
     sc = np.abs(Dp[ok]) * 100.0 / relp[ok]
     assert (np.abs(D.cpu().numpy()[ok] - Dp[ok]) / sc).max() < 1e-11
     gp.close()
+
+
+def test_continuum_bands_equal_per_node_tracking_gpu(es_ctx, monkeypatch):
+    """Same statuses and the same D with the band test (default) and with per-node sign tracking (fallback path for
+    profiles whose node intervals do not overlap), on the grid kernel and on the points kernel."""
+    from eigensolver_amd import ShootProblem, equilibrium as q
+    k = np.linspace(0.05, 4.0, 16)
+    W = np.linspace(0.3, 5.0, 2048)
+    for eq, mode in [(q.CylinderFlow(U_i0=0.7, width=0.9), "kink"), (q.CylinderDensity(width=0.9), "sausage")]:
+        monkeypatch.delenv("ES_FORCE_SIGN_TRACKING", raising=False)
+        gb = ShootProblem(eq, mode, ctx=es_ctx)
+        monkeypatch.setenv("ES_FORCE_SIGN_TRACKING", "1")
+        gt = ShootProblem(eq, mode, ctx=es_ctx)
+        monkeypatch.delenv("ES_FORCE_SIGN_TRACKING")
+        Db, stb = gb.eval_grid(k, W)
+        Dt, stt = gt.eval_grid(k, W)
+        stb, stt = stb.cpu().numpy(), stt.cpu().numpy()
+        assert np.array_equal(stb, stt) and int((stb == 3).sum()) > 100
+        assert np.array_equal(Db.cpu().numpy()[stb == 0], Dt.cpu().numpy()[stb == 0])
+        kk = np.repeat(k, 64)
+        ww = kk * np.tile(W[::32], len(k))
+        Dpb, spb = gb.eval_points(kk, ww)
+        Dpt, spt = gt.eval_points(kk, ww)
+        assert np.array_equal(spb.cpu().numpy(), spt.cpu().numpy())
+        gb.close()
+        gt.close()
