@@ -57,6 +57,15 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
       ExteriorLite X[PTS];
 #pragma unroll
       for (int p = 0; p < PTS; ++p) X[p] = exterior_lite(P, k, w[p], w[p]);
+      // a wave none of whose points has an evanescent exterior (leaky / non-finite: D is NaN whatever the march gives)
+      // only takes part in the LDS staging and the barriers
+      bool lane_live = false;
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) {
+        lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK);
+        zp[p] = 0.0; zq[p] = 0.0;
+      }
+      const bool wave_live = __any(lane_live);
       // adjoint march: chunks from the far end of the interior back to the boundary
       const int nchunks = (nsteps + CH - 1) / CH;
       for (int c = nchunks - 1; c >= 0; --c) {
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
           for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = e[f];
         }
         __syncthreads();
+        if (!wave_live) continue;
         if (c == nchunks - 1) {                        // last node: start vector of the march
           double eL[NE];
 #pragma unroll
@@ -143,12 +153,13 @@ __global__ __launch_bounds__(256) void shoot_points_kernel(ShootDev P, const dou
                                                            const double* __restrict__ wv, int n,
                                                            double* __restrict__ Dout, double* __restrict__ relout,
                                                            uint8_t* __restrict__ stout) {
+  ES_POINT_LDS(FAM);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = i < n;
   const double k = in ? kv[i] : 1.0;
   const double w = in ? wv[i] : 1.0;
   double D, rel; uint8_t st;
-  shoot_point<FAM>(P, k, w, w, D, rel, st);
+  shoot_point<FAM>(P, k, w, w, D, rel, st, es_point_lds);
   if (in) {
     Dout[i] = D;
     stout[i] = st;
@@ -220,6 +231,7 @@ template <int FAM>
 __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
                                                     const double* __restrict__ d_hi, int n, int n_rounds,
                                                     int n_polish, double tol_percent) {
+  ES_POINT_LDS(FAM);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 3, j = lane & 7;
   const int i = blockIdx.x * 8 + g;
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
   double D, rel; uint8_t st;
   for (int it = 0; it < n_rounds; ++it) {
     const double x = lo + (hi - lo) * frac;
-    shoot_point<FAM>(P, k, x, x, D, rel, st);
+    shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     const bool diff = (D * flo < 0.0);                 // NaN products compare false, as in the reference
     const unsigned bits = (unsigned)((__ballot(diff) >> (8 * g)) & 0xFFull);
     const int first = bits ? (__ffs((int)bits) - 1) : 8;         // first point whose sign differs from D(lo)
@@ -246,11 +258,11 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
   }
   // Newton-type polish in fp64: regula-falsi (secant through the bracket ends) steps, every lane of the group the same
   double root = lo + (hi - lo) * 0.5;
-  if (n_polish == 0) shoot_point<FAM>(P, k, root, root, D, rel, st);
+  if (n_polish == 0) shoot_point<FAM>(P, k, root, root, D, rel, st, es_point_lds);
   for (int it = 0; it < n_polish; ++it) {
     double x = lo - flo * (hi - lo) / (fhi - flo);
     if (!(x > lo && x < hi)) x = lo + (hi - lo) * 0.5;           // also catches NaN
-    shoot_point<FAM>(P, k, x, x, D, rel, st);
+    shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     root = x;
     if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }
   }

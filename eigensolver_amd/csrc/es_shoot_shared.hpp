@@ -12,7 +12,7 @@ struct es_problem {
 namespace es_shoot_shared {
 
 constexpr int ES_REFINE_POLISH = 2;   // regula-falsi steps after the 9-section rounds (0: report the bracket midpoint)
-constexpr int CH = 128;   // RK4 steps per LDS chunk: (2*CH+1) * NE * 8 B of LDS (12.3 KiB for NE = 6)
+constexpr int CH = 128;   // RK4 steps per LDS chunk: (2*CH+1) * NE * 8 B of LDS (14.4 KiB for NE = 7)
 
 template <int FAM>
 __device__ __forceinline__ void load_base(const ShootDev& P, int pt, double* b) {
@@ -56,10 +56,15 @@ __device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& 
   if (crossed) st = ES_PT_CONTINUUM;
 }
 
-// One (k, omega) pair per lane.  Base-table indices are wave-uniform -> scalar loads.
+// One (k, omega) pair per lane, unrelated k per lane.  Must be called by ALL threads of the workgroup together (it
+// contains barriers): the k-independent base table is staged chunk by chunk (CH RK4 steps) in the LDS buffer `sb`
+// (FamTraits<FAM>::NB * (2 CH + 1) doubles, point-major) with coalesced loads, and every lane then reads the same
+// LDS address per node (broadcast) and forms its own node entries.  Same arithmetic, in the same order, as the grid
+// kernel.  (Reading the table with wave-uniform scalar loads instead left these latency-bound kernels -- one wave
+// per SIMD or fewer -- waiting ~400 ns per RK4 step.)
 template <int FAM, bool TRACK>
 __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, double w, double w_cst, double& D,
-                                                 double& rel, uint8_t& st) {
+                                                 double& rel, uint8_t& st, double* __restrict__ sb) {
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr int NB = FamTraits<FAM>::NB;
   constexpr bool DIAG = FamTraits<FAM>::DIAG;
@@ -69,22 +74,37 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
   SignTrack trk;
   double b[NB], e[NE], e2[NE];
   const ExteriorLite X = exterior_lite(P, k, w, w_cst);
-  // adjoint march from the last node back to the boundary (same arithmetic as the grid kernel)
-  load_base<FAM>(P, 2 * nsteps, b);
-  make_entry<FAM>(b, s, e);
   Coef B0;
-  coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
-  double zp, zq;
-  adjoint_start(P, B0, zp, zq);
-  for (int j = nsteps - 1; j >= 0; --j) {
-    Coef Bm, B1;
-    load_base<FAM>(P, 2 * j + 1, b);
-    make_entry<FAM>(b, s, e);
-    load_base<FAM>(P, 2 * j, b);
-    make_entry<FAM>(b, s, e2);
-    coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
-    rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
-    B0 = B1;
+  double zp = 0.0, zq = 0.0;
+  // adjoint march from the last node back to the boundary, chunk by chunk
+  const int nchunks = (nsteps + CH - 1) / CH;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int c0 = c * CH;
+    const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
+    __syncthreads();                                   // previous chunk fully consumed
+#pragma unroll
+    for (int f = 0; f < NB; ++f)
+      for (int i = threadIdx.x; i < 2 * nst + 1; i += blockDim.x) sb[i * NB + f] = P.base[(size_t)f * P.npts + 2 * c0 + i];
+    __syncthreads();
+    if (c == nchunks - 1) {                            // last node: start vector of the march
+#pragma unroll
+      for (int f = 0; f < NB; ++f) b[f] = sb[2 * nst * NB + f];
+      make_entry<FAM>(b, s, e);
+      coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
+      adjoint_start(P, B0, zp, zq);
+    }
+    for (int j = nst - 1; j >= 0; --j) {
+      Coef Bm, B1;
+#pragma unroll
+      for (int f = 0; f < NB; ++f) b[f] = sb[(2 * j + 1) * NB + f];
+      make_entry<FAM>(b, s, e);
+#pragma unroll
+      for (int f = 0; f < NB; ++f) b[f] = sb[2 * j * NB + f];
+      make_entry<FAM>(b, s, e2);
+      coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
+      rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+      B0 = B1;
+    }
   }
   const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
   finish_point(P, M, X, TRACK ? trk.crossed() : band_crossed(P, k, w), D, rel, st);
@@ -92,9 +112,12 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
 
 template <int FAM>
 __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
-                                            double& rel, uint8_t& st) {
-  if (FAM == FAM_CYL0 && P.use_bands) shoot_point_impl<FAM, FAM != FAM_CYL0>(P, k, w, w_cst, D, rel, st);   // wave-uniform branch
-  else shoot_point_impl<FAM, true>(P, k, w, w_cst, D, rel, st);
+                                            double& rel, uint8_t& st, double* __restrict__ sb) {
+  if (FAM == FAM_CYL0 && P.use_bands) shoot_point_impl<FAM, FAM != FAM_CYL0>(P, k, w, w_cst, D, rel, st, sb);   // uniform branch
+  else shoot_point_impl<FAM, true>(P, k, w, w_cst, D, rel, st, sb);
 }
+
+// LDS buffer every kernel that calls shoot_point declares
+#define ES_POINT_LDS(FAM) __shared__ double es_point_lds[FamTraits<FAM>::NB * (2 * es_shoot_shared::CH + 1)]
 
 }  // namespace es_shoot_shared

@@ -42,6 +42,7 @@ struct WorkerArgs {
 
 template <int FAM>
 __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
+  ES_POINT_LDS(FAM);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = t < a.ntasks;
   const double k = live ? a.k[t] : 1.0;
@@ -97,10 +98,10 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
         need = true;
       }
     }
-    if (!__any(need)) break;
+    if (!__any(need)) break;                        // workgroup = one wave: the exit is workgroup-uniform
     // ---- one determinant evaluation per lane (dummy for lanes that do not need one) ---------------------------
     double d, rel; uint8_t st;
-    shoot_point<FAM>(P, k, w_eval, a.stale_ext_const ? w_stale : w_eval, d, rel, st);
+    shoot_point<FAM>(P, k, w_eval, a.stale_ext_const ? w_stale : w_eval, d, rel, st, es_point_lds);
     if (need) {
       Frame& f = stk[sp - 1];
       ++f.kk;
