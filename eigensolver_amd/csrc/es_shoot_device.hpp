@@ -357,8 +357,8 @@ __device__ __forceinline__ Exterior exterior_cylinder(const ShootDev& P, double 
   const double gap = xR - xb;
   if (gap < 40.0) {
     double Ib, Ib1, IR, IR1;
-    esb::ie_pair(n, xb, Ib, Ib1);
-    esb::ie_pair(n, xR, IR, IR1);
+    esb::ie_pair_from_k(n, xb, Kb, Kb1, Ib, Ib1);
+    esb::ie_pair_from_k(n, xR, KR, KR1, IR, IR1);
     const double dIb = Ib1 + (dn / xb) * Ib;         // e^-x I_n'(x)
     const double dIR = IR1 + (dn / xR) * IR;
     const double a_s = -(P.ic0 * dKR - g * KR);

@@ -93,6 +93,22 @@ static void ie_pair(int n, double x, double* in_, double* in1) {
   *in1 = ex * pre * (hx / ((double)n + 1.0)) * sb;
 }
 
+/* I_n, I_{n+1} (scaled) from known K_n, K_{n+1}: ratio by Miller's backward recurrence, size from the Wronskian
+   I_n K_{n+1} + I_{n+1} K_n = 1/x */
+static void ie_pair_from_k(int n, double x, double kn, double kn1, double* in_, double* in1) {
+  if (x < 0.5) { ie_pair(n, x, in_, in1); return; }
+  const int M = n + 10 + (int)sqrt(40.0 * x);
+  const double tox = 2.0 / x;
+  double ip = 0.0, ic = 1e-200, ktox = (double)M * tox;
+  for (int k = M; k > n; --k) {
+    double im = fma(ktox, ic, ip);
+    ip = ic; ic = im; ktox -= tox;
+  }
+  double f = ip / ic;
+  *in_ = 1.0 / (x * fma(f, kn, kn1));
+  *in1 = f * *in_;
+}
+
 /* ---- problem ------------------------------------------------------------------------------------------------ */
 typedef struct {
   int family, n_nodes, npts, nb;
@@ -330,8 +346,8 @@ static exterior ext_cyl(const port_problem* P, double k, double w, double w_cst)
   double g = P->ic1 / (sgn * mu), Pv, dPv, gap = xR - xb;
   if (gap < 40.0) {
     double Ib, Ib1, IR, IR1;
-    ie_pair(n, xb, &Ib, &Ib1);
-    ie_pair(n, xR, &IR, &IR1);
+    ie_pair_from_k(n, xb, Kb, Kb1, &Ib, &Ib1);
+    ie_pair_from_k(n, xR, KR, KR1, &IR, &IR1);
     double dIb = Ib1 + (dn / xb) * Ib, dIR = IR1 + (dn / xR) * IR;
     double a_s = -(P->ic0 * dKR - g * KR), b_s = -(g * IR - P->ic0 * dIR), E2 = exp(-2.0 * gap);
     Pv = b_s * Kb + E2 * a_s * Ib;

@@ -19,7 +19,7 @@ def hm():
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
     lib = ctypes.CDLL(so)
-    for f in (lib.hm_ke_pair, lib.hm_ie_pair, lib.hm_jy_pair):
+    for f in (lib.hm_ke_pair, lib.hm_ie_pair, lib.hm_ie_pair_from_k, lib.hm_jy_pair):
         f.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
     return lib
 
@@ -42,6 +42,23 @@ def test_scaled_I(hm):
             hm.hm_ie_pair(n, x, out)
             r0, r1 = sp.ive(n, x), sp.ive(n + 1, x)
             assert abs(out[0] / r0 - 1) < 5e-14 and abs(out[1] / r1 - 1) < 5e-14, (n, x)
+
+
+def test_scaled_I_from_K(hm):
+    """Miller ratio + Wronskian normalisation (the form the exterior solution uses): as accurate as the series."""
+    out = (ctypes.c_double * 2)()
+    worst = 0.0
+    for n in (0, 1, 2, 5, 11, 40):
+        for x in np.concatenate([np.logspace(-3, np.log10(0.5), 30), np.linspace(0.5, 80, 400), np.logspace(np.log10(80), np.log10(700), 40)]):
+            if n > 11 and x < 0.5:
+                continue                               # series fallback: its (x/2)^n/n! prefactor loses ~n ulp
+            hm.hm_ie_pair_from_k(n, x, out)
+            r0, r1 = sp.ive(n, x), sp.ive(n + 1, x)
+            tol = 5e-14 if x < 0.5 else (6e-15 if n <= 11 else 1e-13)   # series fallback below 0.5; K_40 by 40 upward recurrences
+            if x >= 0.5 and n <= 11:
+                worst = max(worst, abs(out[0] / r0 - 1), abs(out[1] / r1 - 1))
+            assert abs(out[0] / r0 - 1) < tol and abs(out[1] / r1 - 1) < tol, (n, x, out[0] / r0 - 1)
+    assert worst < 6e-15
 
 
 def test_J_and_Y(hm):
