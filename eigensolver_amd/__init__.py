@@ -7,3 +7,4 @@ from .solvers import (CylinderNonUniformDensity, CylinderNonUniformFlow, Cylinde
                       SlabNonUniformDensity, SlabNonUniformFlow, SlabUniformFlow)
 from .cyl_uniform import CylinderUniform  # noqa: F401
 from . import postprocess  # noqa: F401
+from .complex_flow import SlabComplexFlow, SlabFlowKH  # noqa: F401

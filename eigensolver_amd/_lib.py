@@ -164,3 +164,21 @@ def _sig(lib):  # noqa: F811
     lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]
     lib.es_shoot_eigenfunction.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
     return lib
+
+
+class ComplexRootTable(C.Structure):
+    _fields_ = [("d_k", C.c_void_p), ("d_w_re", C.c_void_p), ("d_w_im", C.c_void_p), ("d_resid", C.c_void_p),
+                ("d_row", C.c_void_p), ("d_flag", C.c_void_p), ("capacity", C.c_int32)]
+
+
+_orig_sig3 = _sig
+
+
+def _sig(lib):  # noqa: F811
+    _orig_sig3(lib)
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    lib.es_complex_eval_grid.argtypes = [vp, vp, i, vp, i, vp, i, vp, i, i, vp, vp, vp, vp]
+    lib.es_complex_eval_points.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp]
+    lib.es_complex_find_roots.argtypes = [vp, vp, i, vp, i, vp, i, vp, i, i, vp, vp, vp, i, d,
+                                          C.POINTER(ComplexRootTable), C.POINTER(i)]
+    return lib

@@ -11,6 +11,7 @@ extern "C" int es_abi_sizeof(int which) {
     case 3: return (int)sizeof(es_root_table);
     case 4: return (int)sizeof(es_worker_spec);
     case 5: return (int)sizeof(es_cyl_uniform_params);
+    case 6: return (int)sizeof(es_complex_root_table);
     default: return -1;
   }
 }

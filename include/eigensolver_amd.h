@@ -240,6 +240,53 @@ int es_shoot_eigenfunction(es_context* ctx, const es_problem* prob, const double
                            double* d_int_value, double* d_int_flux,            /* n x N      */
                            int n_ext, double* d_ext_x, double* d_ext_value, double* d_ext_flux /* n x n_ext */);
 
+/* ======================================================================================================
+ * (6) Complex frequencies (unstable / Kelvin-Helmholtz modes of the flow slab) -- SURVEY 8f row 3.
+ *     Replaces the determinant evaluation and the (Re omega, Im omega) scan of
+ *       Slab/Non uniform flow/COMPLEX ANALYSIS/flow_multiprocessor_complex_coronal.py
+ *         :348 / :737   sausage / kink(wavenumber, ws, ks, ws_imag, ks_imag, freq)   (6-argument workers)
+ *         :369-404      m_e, p_e_const, m0, D, coeff, P_Ti, add_P_Ti with omega = omega_r + i omega_i
+ *         :419-456      exterior / interior ODEs, boundary value, total pressures
+ *         :1127         driver grid: Re(omega) over a phase-speed band x Im(omega) over [-0.25, 0.25]
+ *     in its consistent reading (everything complex; the reference mixes real and imaginary parts, see
+ *     DESIGN.md): D_c(k, omega) = p_e V_e'/V_e - P_Ti (Vx' - add Vx) at x = -1, the far-end condition
+ *     Vx(+1) = -/+ Vx(-1) imposed by superposition, rel = 100 |D_c| / max(|outer|, |inner|).  Points with
+ *     Re(m_e) < 0 are ES_PT_LEAKY (`if m_e.real < 0: pass`, SF-X:405).  Only for ES_GEOM_SLAB_FLOW problems.
+ *     variant: ES_CX_SFX = the complex script's formulas (D of SF-X:382, P_T with the U' term of SF-X:401, :455);
+ *              ES_CX_SFG = the real script's (D of flow_multiprocessor_coronal.py:421, no U' term): at
+ *              Im(omega) = 0 this is es_shoot_eval_* up to the sign normalisation of the exterior amplitude.
+ *     Grid layout: [(row * n_im + i_im) * n_re + i_re]; w_mode ES_W_ABSOLUTE: omega = w_re + i w_im;
+ *     ES_W_PHASE_SPEED: omega = k (w_re + i w_im).
+ *     es_complex_find_roots: a grid cell holds a root if D_c winds once around 0 along its four corners (quadrant
+ *     count; cells with a non-finite corner are skipped); each such cell is refined by `n_iter` complex secant
+ *     steps from the cell centre; flag = 1 if the final rel < tol_percent and the iterate stayed within two cell
+ *     diagonals of the centre.  Ordered by (row, i_im, i_re).
+ * ====================================================================================================== */
+enum { ES_CX_SFX = 0, ES_CX_SFG = 1 };
+
+int es_complex_eval_grid(es_context* ctx, const es_problem* prob, int variant, const double* d_k, int nk,
+                         const double* d_w_re, int n_re, const double* d_w_im, int n_im, int w_mode,
+                         double* d_D_re, double* d_D_im, double* d_rel /* may be NULL */, uint8_t* d_status);
+
+int es_complex_eval_points(es_context* ctx, const es_problem* prob, int variant, const double* d_k,
+                           const double* d_w_re, const double* d_w_im, int n, double* d_D_re, double* d_D_im,
+                           double* d_rel /* may be NULL */, uint8_t* d_status);
+
+typedef struct es_complex_root_table {
+  double* d_k;
+  double* d_w_re;      /* refined root */
+  double* d_w_im;
+  double* d_resid;     /* rel (percent) at the refined root */
+  int32_t* d_row;
+  int32_t* d_flag;     /* 1 accepted, 0 not converged / left the cell neighbourhood (e.g. a pole) */
+  int32_t capacity;
+} es_complex_root_table;
+
+int es_complex_find_roots(es_context* ctx, const es_problem* prob, int variant, const double* d_k, int nk,
+                          const double* d_w_re, int n_re, const double* d_w_im, int n_im, int w_mode,
+                          const double* d_D_re, const double* d_D_im, const uint8_t* d_status, int n_iter,
+                          double tol_percent, es_complex_root_table* table, int* out_count);
+
 #ifdef __cplusplus
 }
 #endif

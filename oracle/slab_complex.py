@@ -187,3 +187,48 @@ class ComplexFlowSlab:
             rel = np.abs(d) * 100.0 / np.maximum(np.abs(outer), np.abs(inner))
         d = np.where(st == ST_OK, d, np.nan + 0j)
         return d, np.where(st == ST_OK, rel, np.nan), st.astype(np.uint8)
+
+    # ---- root search on a (Re, Im) grid: the algorithm of es_complex_find_roots ------------------------------------
+    @staticmethod
+    def _quadrant(z):
+        return np.where(z.real >= 0, np.where(z.imag >= 0, 0, 3), np.where(z.imag >= 0, 1, 2))
+
+    def find_roots(self, k, w_re, w_im, n_iter=12, tol=4.0, evaluator=None):
+        """Cells of the rectangular grid w_re x w_im around whose corners D_c winds once (quadrant count; an
+        ambiguous half-turn edge also qualifies), refined by complex secant steps from the cell centre.
+        Returns (roots complex array, rel array, flag array) ordered by (i_im, i_re)."""
+        ev = evaluator or self.eval_rk4
+        w_re, w_im = np.asarray(w_re, float), np.asarray(w_im, float)
+        W = (w_re[None, :] + 1j * w_im[:, None])
+        d, rel, st = ev(k, W.ravel())
+        d, st = d.reshape(W.shape), st.reshape(W.shape)
+        q = self._quadrant(d)
+
+        def turns(a, b):
+            t = (b - a) & 3
+            return np.where(t == 0, 0, np.where(t == 1, 1, np.where(t == 3, -1, 8)))
+
+        q00, q10, q11, q01 = q[:-1, :-1], q[:-1, 1:], q[1:, 1:], q[1:, :-1]
+        total = turns(q00, q10) + turns(q10, q11) + turns(q11, q01) + turns(q01, q00)
+        okc = (st[:-1, :-1] == 0) & (st[:-1, 1:] == 0) & (st[1:, 1:] == 0) & (st[1:, :-1] == 0)
+        cand = okc & ((total == 4) | (total == -4) | (total >= 6))
+        roots, rels, flags = [], [], []
+        for im, ire in zip(*np.nonzero(cand)):
+            a, b = W[im, ire], W[im + 1, ire + 1]
+            centre, half = 0.5 * (a + b), 0.5 * (b - a)
+            w0, w1 = centre, centre + 0.5 * half
+            f0, f1 = ev(k, [w0])[0][0], ev(k, [w1])[0][0]
+            for _ in range(n_iter):
+                df = f1 - f0
+                with np.errstate(all="ignore"):
+                    w2 = w1 - f1 * ((w1 - w0) / df)
+                if not np.isfinite(w2) or df == 0:
+                    w2 = w1
+                w0, f0, w1 = w1, f1, w2
+                f1 = ev(k, [w1])[0][0]
+                if not np.isfinite(f1):
+                    w1, f1 = w0, f0
+            dd, rr, ss = ev(k, [w1])
+            ok = ss[0] == 0 and rr[0] < tol and abs(w1 - centre) ** 2 <= 16.0 * abs(half) ** 2
+            roots.append(w1); rels.append(rr[0]); flags.append(1 if ok else 0)
+        return np.array(roots, dtype=complex), np.array(rels), np.array(flags, dtype=int)

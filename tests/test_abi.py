@@ -51,7 +51,7 @@ def test_ctypes_struct_layouts_match_the_library():
     lib.es_abi_sizeof.restype = ctypes.c_int
     lib.es_abi_sizeof.argtypes = [ctypes.c_int]
     mirrors = [_lib.SlabAnalyticParams, _lib.ShootDesc, _lib.Profiles, _lib.RootTable, _lib.WorkerSpec,
-               _lib.CylUniformParams]
+               _lib.CylUniformParams, _lib.ComplexRootTable]
     for i, m in enumerate(mirrors):
         assert lib.es_abi_sizeof(i) == ctypes.sizeof(m), (i, m.__name__, lib.es_abi_sizeof(i), ctypes.sizeof(m))
     assert lib.es_abi_sizeof(1) == ctypes.sizeof(port.ShootDesc) and lib.es_abi_sizeof(2) == ctypes.sizeof(port.Profiles)
