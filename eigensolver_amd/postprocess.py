@@ -62,3 +62,41 @@ def from_root_table(roots, accepted_only=True):
         sel = roots["flag"].detach().cpu().numpy() == 1
         w, k = w[sel], k[sel]
     return w, k
+
+
+def write_vtk(dump_file, x, y, z, variables, names):
+    """Legacy-VTK structured-grid dump of scalar fields on an irregular grid, byte for byte what the reference's
+    `makeDumpVTK(x, y, z, variables, varList, dumpFile)` writes (Cylinder/Non-uniform density/Coronal/Movies/
+    Export_vtk.py:70-112): header lines as there (trailing blanks included), BINARY, big-endian float32, points as
+    interleaved (x, y, z) with the first index fastest, one `SCALARS <name> float` block per variable.
+    x, y, z and every variable are arrays of the same shape (ax, ay, az).  Writes `<dump_file>.vtk`."""
+    x, y, z = (np.asarray(a, dtype=np.float64) for a in (x, y, z))
+    if not (x.ndim == 3 and x.shape == y.shape == z.shape):
+        raise ValueError("x, y, z must be 3-D arrays of one shape")
+    if len(variables) != len(names):
+        raise ValueError("one name per variable")
+    ax, ay, az = x.shape
+    n = ax * ay * az
+
+    def packed(a):                     # loop order k, j, i with i fastest = Fortran order of an (i, j, k) array
+        return np.asarray(a, dtype=np.float64).astype(">f4").ravel(order="F")
+
+    with open(str(dump_file) + ".vtk", "wb") as f:
+        f.write(b"# vtk DataFile Version 3.0 \n")
+        f.write(b"vtk output \n")
+        f.write(b"BINARY \n")
+        f.write(b"DATASET STRUCTURED_GRID \n")
+        f.write(("DIMENSIONS  %s %s %s  \n" % (ax, ay, az)).encode())
+        f.write(("POINTS %s float  \n" % n).encode())
+        pts = np.empty((n, 3), dtype=">f4")
+        pts[:, 0], pts[:, 1], pts[:, 2] = packed(x), packed(y), packed(z)
+        f.write(pts.tobytes())
+        f.write(("\nPOINT_DATA %s  " % n).encode())
+        for name, var in zip(names, variables):
+            var = np.asarray(var)
+            if var.shape != x.shape:
+                raise ValueError(f"variable {name!r} has shape {var.shape}, grid is {x.shape}")
+            f.write(("\nSCALARS %s float \n" % name).encode())
+            f.write(b"LOOKUP_TABLE default \n")
+            f.write(packed(var).tobytes())
+    return str(dump_file) + ".vtk"

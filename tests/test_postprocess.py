@@ -5,6 +5,7 @@ import pickle
 import pickletools
 
 import numpy as np
+import pytest
 
 from eigensolver_amd import postprocess as pp
 from tests import stored_sets as S
@@ -45,3 +46,33 @@ def test_pickle_layout_roundtrip(tmp_path):
     assert len(a) == 4 and all(isinstance(x, np.ndarray) and x.dtype == np.float64 and x.ndim == 1 for x in a)
     assert np.array_equal(a[0], res["sausage"][0]) and np.array_equal(a[3], res["kink"][1])
     assert len(pp.pickle_layout({"kink": (np.zeros(2), np.ones(2))})) == 2       # rotational scripts: [w, k]
+
+
+def test_vtk_dump_layout(tmp_path):
+    """Legacy-VTK structured grid as Export_vtk.py:70-112 writes it: header text, big-endian float32, (x, y, z)
+    interleaved with the first index fastest, one SCALARS block per variable -- checked against an element-by-element
+    packer."""
+    import struct
+    rng = np.random.default_rng(0)
+    shape = (3, 4, 2)
+    x, y, z = (rng.normal(size=shape) for _ in range(3))
+    v1, v2 = rng.normal(size=shape), rng.normal(size=shape)
+    path = pp.write_vtk(tmp_path / "dump", x, y, z, [v1, v2], ["P", "xi_r"])
+    got = open(path, "rb").read()
+    ax, ay, az = shape
+    want = b"# vtk DataFile Version 3.0 \nvtk output \nBINARY \nDATASET STRUCTURED_GRID \n"
+    want += b"DIMENSIONS  3 4 2  \nPOINTS 24 float  \n"
+    for k in range(az):
+        for j in range(ay):
+            for i in range(ax):
+                want += struct.pack(">f", x[i, j, k]) + struct.pack(">f", y[i, j, k]) + struct.pack(">f", z[i, j, k])
+    want += b"\nPOINT_DATA 24  "
+    for name, v in (("P", v1), ("xi_r", v2)):
+        want += b"\nSCALARS " + name.encode() + b" float \nLOOKUP_TABLE default \n"
+        for k in range(az):
+            for j in range(ay):
+                for i in range(ax):
+                    want += struct.pack(">f", v[i, j, k])
+    assert got == want
+    with pytest.raises(ValueError):
+        pp.write_vtk(tmp_path / "bad", x, y, z, [v1[:2]], ["P"])
