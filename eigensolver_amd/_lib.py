@@ -36,8 +36,6 @@ def _sig(lib):
     lib.es_slab_analytic_eval.argtypes = [vp, P, i, vp, i, vp, i, vp]
     lib.es_slab_analytic_scan.argtypes = [vp, P, i, vp, i, vp, i, d, vp, vp, i, C.POINTER(i)]
     lib.es_slab_analytic_filter.argtypes = [vp, P, i, vp, vp, i, d, vp]
-    for name in dir(lib):
-        pass
     return lib
 
 
@@ -48,6 +46,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise EsError(f"{LIB_PATH} not found: build it with `python -m eigensolver_amd.build` "
                           "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        # Device memory and streams come from torch, and the torch wheel carries its own HIP runtime: it has to be
+        # the first one in the process (loading this library before torch leaves two runtimes, and the second one
+        # finds no device).
+        import torch  # noqa: F401
         _lib = _sig(C.CDLL(LIB_PATH))
     return _lib
 
