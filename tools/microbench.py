@@ -82,3 +82,19 @@ for variant in ("0", "1", "2"):
     t = timeit(lambda: rot.eval_grid(k2, W2), reps=3)
     print(f"K3 rotational (FAM_CYLT, {n2}x{n2}, N=2000) variant {variant}: {t*1e3:.1f} ms -> {n2*n2/t/1e6:.1f} M det-evals/s")
 del os.environ["ES_GRID_VARIANT"]
+
+# K6 complex-frequency flow slab: 256 k x (64 x 64) (Re, Im) grid, N = 500, + root search
+from eigensolver_amd import SlabComplexFlow  # noqa: E402
+from eigensolver_amd.shooting import W_PHASE_SPEED  # noqa: E402
+
+cxs = SlabComplexFlow(width=0.9, ctx=ctx)
+kc = np.linspace(0.05, 2.5, 256)
+wr, wi = np.linspace(-0.5, 2.5, 64), np.linspace(-0.3, 0.3, 64)
+t = timeit(lambda: cxs.eval_grid("kink", kc, wr, wi, W_PHASE_SPEED), reps=3)
+print(f"K6 complex flow slab (256 k x 64 x 64, N=500): {t*1e3:.1f} ms -> {256*64*64/t/1e6:.1f} M det-evals/s")
+Dc, sc, rc = cxs.eval_grid("kink", kc, wr, wi, W_PHASE_SPEED)
+torch.cuda.synchronize()
+tt = time.time()
+roots, cnt = cxs.find_roots("kink", kc, wr, wi, Dc, sc, W_PHASE_SPEED)
+torch.cuda.synchronize()
+print(f"K6 root search: {cnt} candidate cells, {int((roots['flag'] == 1).sum())} accepted, {(time.time()-tt)*1e3:.1f} ms")
