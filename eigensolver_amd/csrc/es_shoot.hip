@@ -1,14 +1,14 @@
-// K3/K4/K5: shooting evaluation of D(k, omega) on a (k, omega) grid, bracket detection, bisection refinement and
-// ordered root compaction.  See es_shoot_device.hpp for the arithmetic and include/eigensolver_amd.h for the
+// K3/K4/K5: shooting evaluation of D(k, omega) on a (k, omega) grid, bracket detection, 9-section + secant refinement
+// and ordered root compaction.  See es_shoot_device.hpp for the arithmetic and include/eigensolver_amd.h for the
 // reference lines each entry point replaces.
 //
 // Kernel layout (DESIGN.md section "kernels"):
-//  * shoot_grid_kernel<FAM, PTS>: one workgroup per k-row, omega along the lanes (PTS points per lane, strided by
+//  * shoot_grid_kernel<FAM, PTS, MAXT, TRACK>: one workgroup per k-row, omega along the lanes (PTS points per lane, strided by
 //    the workgroup size so the 8-byte D stores of a wave are one contiguous 512 B segment).  k is workgroup
 //    uniform, so everything that depends on (node, k, m) but not on omega is computed ONCE per row into an LDS
 //    table, chunk by chunk (CH RK4 steps per chunk); every lane then reads the same LDS address (broadcast).
 //  * shoot_points_kernel<FAM>: one (k, omega) pair per lane with unrelated k: the k-independent base table is
-//    read with wave-uniform addresses (scalar loads), node entries are formed per lane.  Used for refinement.
+//    staged in LDS chunk by chunk (es_shoot_shared.hpp: shoot_point), node entries are formed per lane.
 //  * bracket_flag_kernel: sign change against the omega-neighbour through __shfl_down (lane 63 reads the halo
 //    element), ballot masks + per-block counts; bracket_emit_kernel writes the ordered bracket list.
 //  * refine_kernel: 8 lanes per bracket, 9-section rounds steered by a wave ballot (uniform trip count -> no
@@ -285,7 +285,8 @@ int check_problem(es_context* ctx, const es_problem* prob) {
 //   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)
 //   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD, no scratch)  -- default for rows >= 2048 wide
 //   variant 2: PTS = 1, up to 1024 threads                                         -- narrow rows (worker batches)
-// Variants 0 and 1 run at the same speed (the kernel is VALU-issue bound, measured 35.9 ms both at 4096^2).
+// Variant 1 is the fastest on wide rows (FAM_CYL0, 4096^2: 26 ms against 30 ms for variants 0 / 2): four
+// independent points per lane cover the fp64 dependency chains and share the broadcast LDS reads.
 // ES_GRID_VARIANT in the environment overrides the default (tuning aid).
 template <int FAM>
 int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,

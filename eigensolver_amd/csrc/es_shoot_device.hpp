@@ -172,8 +172,8 @@ __device__ __forceinline__ bool band_crossed(const ShootDev& P, double k, double
 
 // Coefficient matrix A(x; k, omega) of one node in two parts: everything except ONE reciprocal.  The entries marked
 // "/den" are numerators; coef_finish() multiplies them with 1/den.  The caller computes the reciprocals of the
-// mid-point and end-point denominators of a step with a single IEEE division: inv = 1/(den_m * den_1),
-// 1/den_m = den_1 * inv, 1/den_1 = den_m * inv  (one v_div sequence per RK4 step instead of two).
+// mid-point and end-point denominators of a step with a single reciprocal (fast_rcp): inv = 1/(den_m * den_1),
+// 1/den_m = den_1 * inv, 1/den_1 = den_m * inv  (one reciprocal per RK4 step instead of two).
 struct CoefPre { double n11, n12, n21, n22, den; };
 
 template <int FAM, bool TRACK = true>
