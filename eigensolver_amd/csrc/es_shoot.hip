@@ -285,7 +285,7 @@ int check_problem(es_context* ctx, const es_problem* prob) {
 //   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)
 //   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD, no scratch)  -- default for rows >= 2048 wide
 //   variant 2: PTS = 1, up to 1024 threads                                         -- narrow rows (worker batches)
-// Variant 1 is the fastest on wide rows (FAM_CYL0, 4096^2: 26 ms against 30 ms for variants 0 / 2): four
+// Variant 1 is the fastest on wide rows (FAM_CYL0, 4096^2: 26.2 ms against 27.6 / 30.0 ms for variants 0 / 2): four
 // independent points per lane cover the fp64 dependency chains and share the broadcast LDS reads.
 // ES_GRID_VARIANT in the environment overrides the default (tuning aid).
 template <int FAM>
