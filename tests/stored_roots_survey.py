@@ -2,7 +2,7 @@
 tests/stored_sets.describe() infers, print the accepted fraction per file / mode and write the regression floors
 tests/golden/stored_roots_floors.json  (floor = observed fraction rounded down to 0.05, minus 0.05).
 
-    python tools/stored_roots_survey.py [--write]
+    python tests/stored_roots_survey.py [--write]
 """
 import json
 import math
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 from tests import cases, stored_sets as S  # noqa: E402
 

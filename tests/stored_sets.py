@@ -14,7 +14,7 @@ fill [0, tol) and stop sharply at tol (e.g. cylinder flow kink: 386 roots in [0.
 pins the oracle's measure to the reference's to about a percent (test_acceptance_measure_cutoff).  Exception: the
 rotational sausage_fast files, whose refined roots were accepted with the stale exterior constant of CR-SF:617 that a
 pointwise re-evaluation cannot know; their measures tail off smoothly above 1.5.  FLOORS (golden/stored_roots_floors.json, written by
-tools/stored_roots_survey.py) holds the minimum accepted fraction per file and mode; files listed in UNPINNED are
+tests/stored_roots_survey.py) holds the minimum accepted fraction per file and mode; files listed in UNPINNED are
 carried as data but not asserted, with the reason."""
 import json
 import os
