@@ -22,23 +22,6 @@ class EsError(RuntimeError):
 _lib = None
 
 
-def _sig(lib):
-    vp, i, d = C.c_void_p, C.c_int, C.c_double
-    lib.es_abi_version.restype = i
-    lib.es_status_string.restype = C.c_char_p
-    lib.es_status_string.argtypes = [i]
-    lib.es_context_create.argtypes = [i, vp, C.POINTER(vp)]
-    lib.es_context_destroy.argtypes = [vp]
-    lib.es_last_error.restype = C.c_char_p
-    lib.es_last_error.argtypes = [vp]
-    lib.es_context_synchronize.argtypes = [vp]
-    P = C.POINTER(SlabAnalyticParams)
-    lib.es_slab_analytic_eval.argtypes = [vp, P, i, vp, i, vp, i, vp]
-    lib.es_slab_analytic_scan.argtypes = [vp, P, i, vp, i, vp, i, d, vp, vp, i, C.POINTER(i)]
-    lib.es_slab_analytic_filter.argtypes = [vp, P, i, vp, vp, i, d, vp]
-    return lib
-
-
 def load():
     """Load the shared library (once).  Raises EsError if it has not been built."""
     global _lib
@@ -132,40 +115,10 @@ class WorkerSpec(C.Structure):
                 ("stale_ext_const", C.c_int32), ("reserved", C.c_int32)]
 
 
-def _sig_shoot(lib):
-    vp, i, d = C.c_void_p, C.c_int, C.c_double
-    lib.es_problem_create.argtypes = [vp, C.POINTER(ShootDesc), C.POINTER(Profiles), C.POINTER(vp)]
-    lib.es_problem_destroy.argtypes = [vp, vp]
-    lib.es_shoot_eval_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, vp]
-    lib.es_shoot_eval_points.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
-    lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
-    lib.es_worker_run.argtypes = [vp, vp, C.POINTER(WorkerSpec), vp, i, vp, i, vp, vp, i, vp]
-
-
-_orig_sig = _sig
-
-
-def _sig(lib):  # noqa: F811
-    _orig_sig(lib)
-    _sig_shoot(lib)
-    return lib
-
-
 class CylUniformParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("c_i", "vA_i", "rho_i", "U_i", "rho_e", "vA_e", "c_e", "cT_e",
                                            "r_boundary", "r_axis", "L_factor", "ic_value", "ic_slope")] + \
                [("m", C.c_int32), ("m_ext", C.c_int32), ("axis_bc", C.c_int32), ("reserved", C.c_int32)]
-
-
-_orig_sig2 = _sig
-
-
-def _sig(lib):  # noqa: F811
-    _orig_sig2(lib)
-    vp, i = C.c_void_p, C.c_int
-    lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]
-    lib.es_shoot_eigenfunction.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
-    return lib
 
 
 class ComplexRootTable(C.Structure):
@@ -173,12 +126,33 @@ class ComplexRootTable(C.Structure):
                 ("d_row", C.c_void_p), ("d_flag", C.c_void_p), ("capacity", C.c_int32)]
 
 
-_orig_sig3 = _sig
-
-
-def _sig(lib):  # noqa: F811
-    _orig_sig3(lib)
+def _sig(lib):
+    """Argument / result types of every entry point of include/eigensolver_amd.h (sections in header order)."""
     vp, i, d = C.c_void_p, C.c_int, C.c_double
+    lib.es_abi_version.restype = i
+    lib.es_status_string.restype = C.c_char_p
+    lib.es_status_string.argtypes = [i]
+    lib.es_context_create.argtypes = [i, vp, C.POINTER(vp)]
+    lib.es_context_destroy.argtypes = [vp]
+    lib.es_last_error.restype = C.c_char_p
+    lib.es_last_error.argtypes = [vp]
+    lib.es_context_synchronize.argtypes = [vp]
+    # (1) closed-form slab
+    P = C.POINTER(SlabAnalyticParams)
+    lib.es_slab_analytic_eval.argtypes = [vp, P, i, vp, i, vp, i, vp]
+    lib.es_slab_analytic_scan.argtypes = [vp, P, i, vp, i, vp, i, d, vp, vp, i, C.POINTER(i)]
+    lib.es_slab_analytic_filter.argtypes = [vp, P, i, vp, vp, i, d, vp]
+    # (2) shooting determinant, brackets, refinement; (3) worker
+    lib.es_problem_create.argtypes = [vp, C.POINTER(ShootDesc), C.POINTER(Profiles), C.POINTER(vp)]
+    lib.es_problem_destroy.argtypes = [vp, vp]
+    lib.es_shoot_eval_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, vp]
+    lib.es_shoot_eval_points.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
+    lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
+    lib.es_worker_run.argtypes = [vp, vp, C.POINTER(WorkerSpec), vp, i, vp, i, vp, vp, i, vp]
+    # (4) closed-form uniform cylinder; (5) eigenfunctions
+    lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]
+    lib.es_shoot_eigenfunction.argtypes = [vp, vp, vp, vp, i, vp, vp, i, vp, vp, vp]
+    # (6) complex frequencies
     lib.es_complex_eval_grid.argtypes = [vp, vp, i, vp, i, vp, i, vp, i, i, vp, vp, vp, vp]
     lib.es_complex_eval_points.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp]
     lib.es_complex_find_roots.argtypes = [vp, vp, i, vp, i, vp, i, vp, i, i, vp, vp, vp, i, d,
