@@ -9,7 +9,9 @@ Workload (BASELINE.json configs[3], the configuration the metric is quoted on): 
 (Gaussian) axial flow, coronal constants of Cylinder_method_flow_testing.py:69-72, 4096 x 4096 (k, omega) grid,
 fp64; k = linspace(0.01, 4, 4096), omega = k * W, W half-cell centred in (cT_i0, vA_e).
 One "step" = one pass of the hot path over that grid on each GPU: D(k, omega) at every grid point (HIP propagator),
-bracket detection (wave shuffle + ballot), bisection refinement, ordered root compaction.
+bracket detection (wave shuffle + ballot), 9-section + secant refinement, ordered root compaction.
+The kernels run on torch's current stream of the device (the stream the es_context is created with), so the
+torch.cuda.Event pairs around the grid launch time exactly that kernel.
 Multi-GPU: the (k, m) grid tiles across ranks with no data-path collective -- rank r solves azimuthal order
 m = r + 1 on the full (k, omega) grid (weak scaling); the only exchange is one RCCL all-gather of the root tables.
 

@@ -52,11 +52,12 @@ def make_desc(eq, mode, m=None):
 class ShootProblem:
     """One reference worker configuration resident on the GPU (profile tables in HBM)."""
 
-    def __init__(self, eq, mode, m=None, ctx=None):
-        import torch  # noqa: F401
+    def __init__(self, eq, mode, m=None, ctx=None, accept_norm=0):
+        """accept_norm = 1: `rel` is normalised by |outer| only (CR-KS:722) instead of max(|outer|, |inner|)."""
         self.ctx = ctx if ctx is not None else _lib.Context()
         self.eq, self.mode = eq, mode
         self.desc, prof = make_desc(eq, mode, m)
+        self.desc.accept_norm = int(accept_norm)
         self._prof_np = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in prof.items()}
         p = _lib.Profiles()
         for name in _lib._PROFILE_FIELDS:

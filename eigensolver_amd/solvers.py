@@ -18,7 +18,6 @@ checked-in tolerances / recursion caps of its workers, its frequency-band builde
     Cylinder/Rotational flow/Photospheric/Solvers/Twisted_photospheric_*.py               CylinderRotationalFlow
 """
 import ctypes as C
-import math
 
 import numpy as np
 
@@ -46,26 +45,9 @@ class _WorkerSolver:
 
     def problem(self, mode):
         if mode not in self._problems:
-            p = ShootProblem.__new__(ShootProblem)
-            # accept_norm is part of the problem (it defines `rel`), so set it before creation
-            self._init_problem(p, mode)
-            self._problems[mode] = p
+            # accept_norm is part of the problem (it defines `rel`)
+            self._problems[mode] = ShootProblem(self.eq, mode, ctx=self.ctx, accept_norm=int(self.WORKER[mode][5]))
         return self._problems[mode]
-
-    def _init_problem(self, p, mode):
-        from .shooting import make_desc
-        spec = self.WORKER[mode]
-        p.ctx, p.eq, p.mode = self.ctx, self.eq, mode
-        p.desc, prof = make_desc(self.eq, mode)
-        p.desc.accept_norm = int(spec[5])
-        p._prof_np = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in prof.items()}
-        pr = _lib.Profiles()
-        for name in _lib._PROFILE_FIELDS:
-            a = p._prof_np.get(name)
-            setattr(pr, name, a.ctypes.data if a is not None else None)
-        h = C.c_void_p()
-        _lib.check(self.ctx.handle, self.ctx.lib.es_problem_create(self.ctx.handle, C.byref(p.desc), C.byref(pr), C.byref(h)))
-        p.handle = h
 
     def worker_spec(self, mode, tol=None):
         t = self.WORKER[mode]
