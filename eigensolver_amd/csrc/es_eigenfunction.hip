@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void eigen_interior_kernel(ShootDev P, const do
     load_base<FAM>(P, 2 * j, b);
     make_entry<FAM>(b, s, e2);
     coefficients2<FAM>(e, e2, P, s, w, Bm, B1, trk);
-    rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+    rk4_step_adjoint<FamTraits<FAM>::SHAPE>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
     B0 = B1;
   }
   // boundary state from the same algebra as the determinant

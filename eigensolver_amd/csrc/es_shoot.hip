@@ -29,7 +29,6 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
                                                           double* __restrict__ Dout, double* __restrict__ relout,
                                                           uint8_t* __restrict__ stout) {
   constexpr int NE = FamTraits<FAM>::NE;
-  constexpr bool DIAG = FamTraits<FAM>::DIAG;
   constexpr int LSTRIDE = 2 * CH + 1;
   // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
   constexpr bool PAIR = (FAM == FAM_CYL0) && (PTS == 4) && !TRACK;
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
           _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                 \
             Coef Bm;                                                                        \
             coefficients2<FAM, TRACK>(em, e1, P, s, w[p], Bm, BOUT[p], trk[p]);             \
-            rk4_step_adjoint<DIAG>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);       \
+            rk4_step_adjoint<FamTraits<FAM>::SHAPE>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);       \
           }                                                                                 \
         }
         int j = nst - 1;
@@ -300,13 +299,13 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
     if (T > maxT) T = maxT;
     return T;
   };
-  // FAM_CYL0 with connected continuum bands: no per-node sign tracking (band_crossed)
-  const bool bands = (FAM == FAM_CYL0) && prob->dev.use_bands;
+  // families with connected continuum bands: no per-node sign tracking (band_crossed)
+  const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
 #define ES_LAUNCH_GRID(PTS, MAXT, T)                                                                                \
   do {                                                                                                              \
-    if (FAM == FAM_CYL0 && bands)                                                                                   \
-      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, FAM != FAM_CYL0>), dim3(grid), dim3(T), 0, ctx->stream, \
-                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                \
+    if (bands)                                                                                                      \
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, !fam_has_bands<FAM>()>), dim3(grid), dim3(T), 0,        \
+                         ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                   \
     else                                                                                                            \
       hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, true>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, \
                          d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                           \
@@ -456,21 +455,30 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
   S.cT2_i = (S.S_i > 0.0) ? S.c2_i * S.vA2_i / S.S_i : 0.0;
   S.rho_i = d->rho_i;
   S.accept_norm = d->accept_norm;
-  if (d->geometry == ES_GEOM_CYLINDER) {
-    // continuum bands in phase speed (band_crossed): node intervals |W - vz| < |bA| (Alfven), < |bA| sqrt(q) (cusp)
+  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_SLAB_FLOW) {
+    // continuum bands in phase speed (band_crossed): node j is inside band t iff centre_j - a_j < W < centre_j + a_j
+    //   cylinder:  centre = v_z,  a = |bA| (Alfven), |bA| sqrt(q) (cusp)
+    //   flow slab: centre = U,    a = c_i, cT_i, vA_i (uniform) and the half line W < U_j (sign of Om)
+    const bool cyl = (d->geometry == ES_GEOM_CYLINDER);
     S.use_bands = 1;
-    for (int t = 0; t < 2; ++t) {
+    S.n_bands = cyl ? 2 : 4;
+    const double slab_a[3] = {sqrt(S.c2_i), sqrt(S.cT2_i), sqrt(S.vA2_i)};
+    for (int t = 0; t < S.n_bands; ++t) {
       double lo_min = INFINITY, lo_max = -INFINITY, hi_min = INFINITY, hi_max = -INFINITY, lo_prev = 0.0, hi_prev = 0.0;
+      const bool half_line = (!cyl && t == 3);
       for (int i = 0; i < npts; ++i) {
-        const double a = fabs(B(C0_BA, i)) * (t == 0 ? 1.0 : sqrt(B(C0_Q, i)));
-        const double lo = B(C0_VZ, i) - a, hi = B(C0_VZ, i) + a;
-        if (!(a > 0.0) || !std::isfinite(a)) S.use_bands = 0;                       // empty interval: no union
-        if (i > 0 && !(lo < hi_prev && lo_prev < hi)) S.use_bands = 0;             // consecutive intervals disjoint
+        const double centre = cyl ? B(C0_VZ, i) : B(SF_U, i);
+        const double a = cyl ? fabs(B(C0_BA, i)) * (t == 0 ? 1.0 : sqrt(B(C0_Q, i))) : (half_line ? 0.0 : slab_a[t]);
+        const double lo = half_line ? -INFINITY : centre - a, hi = centre + a;
+        if (!std::isfinite(hi) || (cyl && !(a > 0.0))) S.use_bands = 0;              // empty / undefined interval
+        if (i > 0 && !half_line && a > 0.0 && !(lo < hi_prev && lo_prev < hi)) S.use_bands = 0;   // disjoint neighbours
         lo_min = fmin(lo_min, lo); lo_max = fmax(lo_max, lo);
         hi_min = fmin(hi_min, hi); hi_max = fmax(hi_max, hi);
         lo_prev = lo; hi_prev = hi;
       }
       S.band[t][0] = lo_min; S.band[t][1] = lo_max; S.band[t][2] = hi_min; S.band[t][3] = hi_max;
+      // a speed of zero (e.g. cT_i = 0 without field): the term never changes sign -> band that nothing satisfies
+      if (!cyl && !half_line && !(slab_a[t] > 0.0)) { S.band[t][0] = INFINITY; S.band[t][3] = -INFINITY; }
     }
     if (getenv("ES_FORCE_SIGN_TRACKING")) S.use_bands = 0;
   }

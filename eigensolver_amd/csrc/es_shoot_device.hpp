@@ -12,8 +12,8 @@
 //                  P'  = -C1/D P + C3/(r D) Xi ,      Xi' = -r C2/D P + C1/D Xi
 //   FAM_SLABD  slab, non-uniform density (SD-P, SD-C), flux form:  u = Vx, v = F Vx'
 //                  u'  = v/F ,                        v'  = F m0 u = rho (k^2 vA^2 - w^2) u
-//   FAM_SLABF  slab with flow (SF-U uniform, SF-G Gaussian), as written in the reference: u = Vx, v = Vx'
-//                  u'  = v ,                          v'  = -D v - coeff u
+//   FAM_SLABF  slab with flow (SF-U uniform, SF-G Gaussian), the reference's equation: u = Vx, v = Vx'
+//                  u'  = v ,                          v'  = -D v - coeff u      (D, coeff over ONE common denominator)
 // All arithmetic is written out operation by operation (the translation unit is compiled with
 // -ffp-contract=off; fused multiply-adds appear only as explicit fma() calls) and is mirrored line by line by the
 // CPU port in oracle/c/shoot_port.c, so that the two agree to the last bit wherever no libm call is involved.
@@ -44,16 +44,20 @@ struct ShootDev {
   double slab_sign;   // -1 sausage: Vx(+1) = -Vx(-1);  +1 kink
   double c2_i, vA2_i, S_i, cT2_i, rho_i;   // uniform interior speeds of the flow slab
   int accept_norm;    // 0: rel uses max(|outer|,|inner|); 1: |outer| only (CR-KS:722)
-  // FAM_CYL0: continuum bands in phase speed, [term][min lo, max lo, min hi, max hi] (term 0 Alfven, 1 cusp)
-  int use_bands;
-  double band[2][4];
+  // FAM_CYL0 / FAM_SLABF: continuum bands in phase speed, [term][min lo, max lo, min hi, max hi]
+  //   cylinder: term 0 Alfven, 1 cusp;  flow slab: 0 sound, 1 tube, 2 Alfven, 3 Doppler-shifted frequency (lo = -inf)
+  int use_bands, n_bands;
+  double band[4][4];
 };
 
 template <int FAM> struct FamTraits;
-template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 7; static constexpr bool DIAG = false; };
-template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 11, NE = 16; static constexpr bool DIAG = true; };
-template <> struct FamTraits<FAM_SLABD> { static constexpr int NB = 3, NE = 5; static constexpr bool DIAG = false; };
-template <> struct FamTraits<FAM_SLABF> { static constexpr int NB = 3, NE = 3; static constexpr bool DIAG = true; };
+// families whose continuum flag can come from phase-speed bands (band_crossed) instead of per-node sign tracking
+template <int FAM> constexpr bool fam_has_bands() { return FAM == FAM_CYL0 || FAM == FAM_SLABF; }
+// SHAPE of A for the adjoint march: 0 off-diagonal (a11 = a22 = 0), 1 full, 2 companion (a11 = 0, a12 = 1)
+template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 7, SHAPE = 0; static constexpr bool DIAG = false; };
+template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 11, NE = 16, SHAPE = 1; static constexpr bool DIAG = true; };
+template <> struct FamTraits<FAM_SLABD> { static constexpr int NB = 3, NE = 5, SHAPE = 0; static constexpr bool DIAG = false; };
+template <> struct FamTraits<FAM_SLABF> { static constexpr int NB = 3, NE = 4, SHAPE = 2; static constexpr bool DIAG = true; };
 
 // base-field indices
 enum { C0_VZ = 0, C0_BA, C0_Q, C0_A1, C0_B1, C0_E1, C0_E2 };
@@ -130,6 +134,7 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
     e[0] = s.k * b[SF_U];
     e[1] = s.k * b[SF_DU];
     e[2] = s.k * b[SF_DDU];
+    e[3] = 2.0 * e[1];
   }
 }
 
@@ -152,17 +157,16 @@ struct SignTrack {
   }
 };
 
-// FAM_CYL0 without per-node tracking (ShootDev::use_bands): omega_A^2 = k^2 bA^2 and the Doppler shift k v_z scale
+// FAM_CYL0 / FAM_SLABF without per-node tracking (ShootDev::use_bands): omega_A^2 = k^2 bA^2 and the Doppler shift k v_z scale
 // with k, so  t1_j < 0  <=>  |W - vz_j| < |bA_j|  with W = omega/k, an interval (lo_j, hi_j) that does not depend on
 // k.  When consecutive intervals overlap (checked on the host at problem creation) their union is
 // (min lo, max hi) and  "negative at some node but not at all nodes"  <=>  W in (min lo, max hi) and not
 // (max lo < W < min hi): four comparisons per point instead of four integer ops per node.  Same for the cusp term
-// with |bA_j| sqrt(q_j).
+// with |bA_j| sqrt(q_j), and for the flow slab with |W - U_j| < c_i, c_Ti, vA_i and W < U_j (lo = -infinity).
 __device__ __forceinline__ bool band_crossed(const ShootDev& P, double k, double w) {
   const double W = w / k;
   bool c = false;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < P.n_bands; ++t) {
     const bool some = (W > P.band[t][0]) && (W < P.band[t][3]);
     const bool all = (W > P.band[t][1]) && (W < P.band[t][2]);
     c = c || (some && !all);
@@ -218,20 +222,24 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     C.n21 = e[4] * n3;                                   // F m0
     C.den = e[3] * n2;
   } else {
+    // m0, D and coeff of SF-G:416-427 over the common denominator den = S t Om^2 n1 (t = Om^2 - k^2 cT^2,
+    // n1 = k^2 c^2 - Om^2, n3 = k^2 vA^2 - Om^2, G = S t^2 + k^4 cT^2 c^2):
+    //   m0 = -n1 n3 / (S t),   D = -2 k U' G Om / den,   coeff = (k U'' S t Om n1 - 2 (k U')^2 G + n1^2 n3 Om^2) / den
     const double Om = w - e[0];
     const double Om2 = Om * Om;
     const double t = Om2 - s.kcT2;
     const double n1 = s.kc2 - Om2;
     const double n3 = s.kvA2 - Om2;
     if (TRACK) { st.add(0, n1); st.add(1, t); st.add(2, n3); st.add(3, Om); }
-    const double m0 = (n1 * n3) / (P.S_i * (s.kcT2 - Om2));                              // SF-G:416
-    const double Dref = 2.0 * e[1] * (t + s.k4c / (P.S_i * t)) / (Om * (Om2 - s.kc2));   // SF-G:421
-    const double coeff = e[2] / Om + e[1] * Dref / Om - m0;                              // SF-G:427
+    const double St = P.S_i * t;
+    const double G = fma(St, t, s.k4c);
+    const double X = Om * n1;
+    const double g2 = e[3] * G;                          // 2 k U' G
     C.n11 = 0.0;
     C.n12 = 1.0;
-    C.n21 = -coeff;
-    C.n22 = -Dref;
-    C.den = 1.0;                                         // nothing left to divide
+    C.n22 = g2 * Om;                                     // -D                          /den
+    C.n21 = -(fma(e[2], St * X, (n1 * n3) * (n1 * Om2)) - g2 * e[1]);   // -coeff       /den
+    C.den = St * (Om * X);
   }
 }
 
@@ -244,7 +252,7 @@ __device__ __forceinline__ void coef_finish(const CoefPre& C, double inv, Coef& 
   } else if (FAM == FAM_SLABD) {
     A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12 * inv; A.a21 = C.n21;
   } else {
-    A.a11 = C.n11; A.a12 = C.n12; A.a21 = C.n21; A.a22 = C.n22;
+    A.a11 = 0.0; A.a12 = 1.0; A.a21 = C.n21 * inv; A.a22 = C.n22 * inv;
   }
 }
 
@@ -292,12 +300,13 @@ __device__ __forceinline__ void coefficients2(const double* em, const double* e1
 // transposed system taken through the stages in reverse order (A_{j+1}^T, A_{j+1/2}^T, A_j^T), same h.  So the
 // row  r = r_end^T T  is obtained by ONE vector z = (p, q) marched from the far end back to the boundary:
 //      z <- M_j^T z ,   rhs(z) = A^T z = (a11 p + a21 q, a12 p + a22 q).
-template <bool DIAG>
+template <int SHAPE>
 __device__ __forceinline__ void rk4_step_adjoint(double& p, double& q, const Coef& B0, const Coef& Bm, const Coef& B1,
                                                  double h, double h2, double h6, double h3) {
-#define ES_RHS_T(A, pp, qq, kp, kq)                                              \
-  if (DIAG) { kp = fma(A.a11, pp, A.a21 * qq); kq = fma(A.a22, qq, A.a12 * pp); } \
-  else      { kp = A.a21 * qq;                 kq = A.a12 * pp; }
+#define ES_RHS_T(A, pp, qq, kp, kq)                                                          \
+  if (SHAPE == 1)      { kp = fma(A.a11, pp, A.a21 * qq); kq = fma(A.a22, qq, A.a12 * pp); } \
+  else if (SHAPE == 2) { kp = A.a21 * qq;                 kq = fma(A.a22, qq, pp); }         \
+  else                 { kp = A.a21 * qq;                 kq = A.a12 * pp; }
   double k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
   ES_RHS_T(B0, p, q, k1p, k1q);
   tp = fma(h2, k1p, p); tq = fma(h2, k1q, q);

@@ -67,7 +67,6 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
                                                  double& rel, uint8_t& st, double* __restrict__ sb) {
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr int NB = FamTraits<FAM>::NB;
-  constexpr bool DIAG = FamTraits<FAM>::DIAG;
   const KScal s = make_kscal(P, k);
   const int nsteps = P.n_nodes - 1;
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
@@ -102,7 +101,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
       for (int f = 0; f < NB; ++f) b[f] = sb[2 * j * NB + f];
       make_entry<FAM>(b, s, e2);
       coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
-      rk4_step_adjoint<DIAG>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+      rk4_step_adjoint<FamTraits<FAM>::SHAPE>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
       B0 = B1;
     }
   }
@@ -113,7 +112,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
 template <int FAM>
 __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
                                             double& rel, uint8_t& st, double* __restrict__ sb) {
-  if (FAM == FAM_CYL0 && P.use_bands) shoot_point_impl<FAM, FAM != FAM_CYL0>(P, k, w, w_cst, D, rel, st, sb);   // uniform branch
+  if (fam_has_bands<FAM>() && P.use_bands) shoot_point_impl<FAM, !fam_has_bands<FAM>()>(P, k, w, w_cst, D, rel, st, sb);   // uniform branch
   else shoot_point_impl<FAM, true>(P, k, w, w_cst, D, rel, st, sb);
 }
 

@@ -118,8 +118,8 @@ typedef struct {
   int m, m_ext, axis_bc, c1_power;
   double bc_const, slab_sign, c2_i, vA2_i, S_i, cT2_i, rho_i;
   int accept_norm;
-  int use_bands;          /* family 0: continuum flag from phase-speed bands instead of per-node sign tracking */
-  double band[2][4];      /* [Alfven, cusp][min lo, max lo, min hi, max hi] */
+  int use_bands, n_bands; /* families 0 and 3: continuum flag from phase-speed bands instead of per-node sign tracking */
+  double band[4][4];      /* [term][min lo, max lo, min hi, max hi]: cylinder Alfven, cusp; flow slab sound, tube, Alfven, Om */
 } port_problem;
 
 static const int NB_OF[4] = {7, 11, 3, 3};
@@ -161,22 +161,29 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
   P->cT2_i = (P->S_i > 0.0) ? P->c2_i * P->vA2_i / P->S_i : 0.0;
   P->rho_i = d->rho_i;
   P->accept_norm = d->accept_norm;
-  if (d->geometry == ES_GEOM_CYLINDER) {
-    /* node j is inside the Alfven (cusp) continuum of phase speed W iff |W - vz_j| < |bA_j| (|bA_j| sqrt(q_j)); if
-       consecutive node intervals overlap, "inside at some node but not at all" is a test against four numbers */
+  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_SLAB_FLOW) {
+    /* node j is inside band t of phase speed W iff centre_j - a_j < W < centre_j + a_j (cylinder: centre v_z, a = |bA|,
+       |bA| sqrt(q); flow slab: centre U, a = c_i, cT_i, vA_i, and the half line W < U_j); if consecutive node intervals
+       overlap, "inside at some node but not at all" is a test against four numbers */
+    const int cyl = (d->geometry == ES_GEOM_CYLINDER);
     P->use_bands = getenv("ES_FORCE_SIGN_TRACKING") ? 0 : 1;
-    for (int t = 0; t < 2; ++t) {
+    P->n_bands = cyl ? 2 : 4;
+    const double slab_a[3] = {sqrt(P->c2_i), sqrt(P->cT2_i), sqrt(P->vA2_i)};
+    for (int t = 0; t < P->n_bands; ++t) {
       double lo_min = INFINITY, lo_max = -INFINITY, hi_min = INFINITY, hi_max = -INFINITY, lo_prev = 0.0, hi_prev = 0.0;
+      const int half_line = (!cyl && t == 3);
       for (int i = 0; i < npts; ++i) {
-        double a = fabs(P->base[(size_t)1 * npts + i]);
-        if (t == 1) a *= sqrt(P->base[(size_t)2 * npts + i]);
-        double vz = P->base[i], lo = vz - a, hi = vz + a;
-        if (!(a > 0.0) || !isfinite(a)) P->use_bands = 0;
-        if (i > 0 && !(lo < hi_prev && lo_prev < hi)) P->use_bands = 0;
+        double centre = P->base[i], a;
+        if (cyl) { a = fabs(P->base[(size_t)1 * npts + i]); if (t == 1) a *= sqrt(P->base[(size_t)2 * npts + i]); }
+        else a = half_line ? 0.0 : slab_a[t];
+        double lo = half_line ? -INFINITY : centre - a, hi = centre + a;
+        if (!isfinite(hi) || (cyl && !(a > 0.0))) P->use_bands = 0;
+        if (i > 0 && !half_line && a > 0.0 && !(lo < hi_prev && lo_prev < hi)) P->use_bands = 0;
         lo_min = fmin(lo_min, lo); lo_max = fmax(lo_max, lo); hi_min = fmin(hi_min, hi); hi_max = fmax(hi_max, hi);
         lo_prev = lo; hi_prev = hi;
       }
       P->band[t][0] = lo_min; P->band[t][1] = lo_max; P->band[t][2] = hi_min; P->band[t][3] = hi_max;
+      if (!cyl && !half_line && !(slab_a[t] > 0.0)) { P->band[t][0] = INFINITY; P->band[t][3] = -INFINITY; }
     }
   }
   return P;
@@ -184,7 +191,7 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
 static int band_crossed(const port_problem* P, double k, double w) {
   const double W = w / k;
   int c = 0;
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < P->n_bands; ++t) {
     const int some = (W > P->band[t][0]) && (W < P->band[t][3]);
     const int all = (W > P->band[t][1]) && (W < P->band[t][2]);
     c |= (some && !all);
@@ -233,7 +240,7 @@ static void make_entry(const port_problem* P, int pt, const kscal* s, double* e)
       e[0] = s->k2 * c2; e[1] = s->k2 * cT2; e[2] = s->k2 * vA2; e[3] = rho * S; e[4] = rho;
     } break;
     default:
-      e[0] = s->k * b[0]; e[1] = s->k * b[1]; e[2] = s->k * b[2];
+      e[0] = s->k * b[0]; e[1] = s->k * b[1]; e[2] = s->k * b[2]; e[3] = 2.0 * e[1];
   }
 }
 
@@ -270,11 +277,14 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
     } break;
     default: {
       double Om = w - e[0], Om2 = Om * Om, t = Om2 - s->kcT2, n1 = s->kc2 - Om2, n3 = s->kvA2 - Om2;
-      st_add(st, 0, n1); st_add(st, 1, t); st_add(st, 2, n3); st_add(st, 3, Om);
-      double m0 = (n1 * n3) / (P->S_i * (s->kcT2 - Om2));
-      double Dref = 2.0 * e[1] * (t + s->k4c / (P->S_i * t)) / (Om * (Om2 - s->kc2));
-      double cf = e[2] / Om + e[1] * Dref / Om - m0;
-      C->n11 = 0.0; C->n12 = 1.0; C->n21 = -cf; C->n22 = -Dref; C->den = 1.0;
+      if (st) { st_add(st, 0, n1); st_add(st, 1, t); st_add(st, 2, n3); st_add(st, 3, Om); }
+      /* m0, D, coeff of SF-G:416-427 over the common denominator S t Om^2 n1 (G = S t^2 + k^4 cT^2 c^2):
+         D = -2 k U' G Om / den,  coeff = (k U'' S t Om n1 - 2 (k U')^2 G + n1^2 n3 Om^2) / den */
+      double St = P->S_i * t, G = fma(St, t, s->k4c), X = Om * n1, g2 = e[3] * G;
+      C->n11 = 0.0; C->n12 = 1.0;
+      C->n22 = g2 * Om;
+      C->n21 = -(fma(e[2], St * X, (n1 * n3) * (n1 * Om2)) - g2 * e[1]);
+      C->den = St * (Om * X);
     }
   }
 }
@@ -284,7 +294,7 @@ static void coef_finish(const port_problem* P, const coefpre* C, double inv, coe
     case 0: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12; A->a21 = C->n21 * inv; break;
     case 1: A->a11 = C->n11 * inv; A->a22 = C->n22 * inv; A->a12 = C->n12 * inv; A->a21 = C->n21 * inv; break;
     case 2: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12 * inv; A->a21 = C->n21; break;
-    default: A->a11 = C->n11; A->a12 = C->n12; A->a21 = C->n21; A->a22 = C->n22;
+    default: A->a11 = 0.0; A->a12 = 1.0; A->a21 = C->n21 * inv; A->a22 = C->n22 * inv;
   }
 }
 
@@ -399,7 +409,7 @@ int port_eval2(const port_problem* P, double k, double w, double w_cst, double* 
   coef B0, Bm, B1;
   /* adjoint march: one row of the transfer matrix, from the last node back to the boundary */
   make_entry(P, 2 * nsteps, &s, e);
-  strack* tp = (P->family == 0 && P->use_bands) ? NULL : &trk;
+  strack* tp = ((P->family == 0 || P->family == 3) && P->use_bands) ? NULL : &trk;
   coefficients(P, e, &s, w, &B0, tp);
   if (P->family <= 1 && P->axis_bc == ES_AXIS_SAUSAGE) { zp = B0.a11; zq = B0.a12; } else { zp = 1.0; zq = 0.0; }
   for (int j = nsteps - 1; j >= 0; --j) {

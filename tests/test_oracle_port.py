@@ -36,15 +36,18 @@ def test_port_vs_truth(name):
 
 
 def test_continuum_bands_equal_per_node_tracking(monkeypatch):
-    """FAM_CYL0: the phase-speed band test (four comparisons per point) flags exactly the points the per-node sign
-    tracking flags, and leaves D untouched."""
+    """Cylinder (no twist) and flow slab: the phase-speed band test (four comparisons per point and term) flags exactly
+    the points the per-node sign tracking flags, and leaves D untouched."""
     from eigensolver_amd import equilibrium as q
     photo = dict(c_e=1.5, vA_e=0.5, r_sign=1.0, n_nodes=1000, ic=(1e-8, 1e-8))
     k = np.linspace(0.05, 4.0, 24)
-    W = np.linspace(0.3, 5.0, 400)
+    W = np.linspace(0.03, 5.0, 400)
     n_cont = 0
     for eq, mode in [(q.CylinderFlow(U_i0=0.7, width=0.9), "kink"), (q.CylinderDensity(width=0.9), "sausage"),
-                     (q.CylinderDensity(width=1.5, **photo), "kink"), (q.CylinderFlow(U_i0=-0.35, width=3.0), "sausage")]:
+                     (q.CylinderDensity(width=1.5, **photo), "kink"), (q.CylinderFlow(U_i0=-0.35, width=3.0), "sausage"),
+                     (q.SlabFlow(U_i0=0.35, width=1.5), "kink"), (q.SlabFlow(U_i0=0.9, width=0.9), "sausage"),
+                     (q.SlabFlow(c_i0=2.0 / 3.0, vA_i0=1.0, c_e=0.75, vA_e=0.0, U_i0=0.0, U_e=-0.15, width=float("inf"),
+                                 L_factor=7.0), "kink")]:
         monkeypatch.delenv("ES_FORCE_SIGN_TRACKING", raising=False)
         Db, relb, stb = cases.port_problem(eq, mode).eval_grid(k, W, w_mode=1, nthreads=8)
         monkeypatch.setenv("ES_FORCE_SIGN_TRACKING", "1")
