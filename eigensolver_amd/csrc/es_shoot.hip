@@ -455,20 +455,33 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
   S.cT2_i = (S.S_i > 0.0) ? S.c2_i * S.vA2_i / S.S_i : 0.0;
   S.rho_i = d->rho_i;
   S.accept_norm = d->accept_norm;
-  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_SLAB_FLOW) {
+  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_SLAB_FLOW || d->geometry == ES_GEOM_SLAB_DENSITY) {
     // continuum bands in phase speed (band_crossed): node j is inside band t iff centre_j - a_j < W < centre_j + a_j
-    //   cylinder:  centre = v_z,  a = |bA| (Alfven), |bA| sqrt(q) (cusp)
-    //   flow slab: centre = U,    a = c_i, cT_i, vA_i (uniform) and the half line W < U_j (sign of Om)
-    const bool cyl = (d->geometry == ES_GEOM_CYLINDER);
+    //   cylinder:     centre = v_z, a = |bA| (Alfven), |bA| sqrt(q) (cusp)
+    //   flow slab:    centre = U,   a = c_i, cT_i, vA_i (uniform) and the half line W < U_j (sign of Om)
+    //   density slab: centre = 0,   a = c_j, cT_j, vA_j
+    const bool cyl = (d->geometry == ES_GEOM_CYLINDER), flow = (d->geometry == ES_GEOM_SLAB_FLOW);
     S.use_bands = 1;
-    S.n_bands = cyl ? 2 : 4;
+    S.n_bands = cyl ? 2 : (flow ? 4 : 3);
     const double slab_a[3] = {sqrt(S.c2_i), sqrt(S.cT2_i), sqrt(S.vA2_i)};
     for (int t = 0; t < S.n_bands; ++t) {
       double lo_min = INFINITY, lo_max = -INFINITY, hi_min = INFINITY, hi_max = -INFINITY, lo_prev = 0.0, hi_prev = 0.0;
-      const bool half_line = (!cyl && t == 3);
+      const bool half_line = (flow && t == 3);
+      bool never = !cyl;                                   // slab term whose speed is zero at every node
       for (int i = 0; i < npts; ++i) {
-        const double centre = cyl ? B(C0_VZ, i) : B(SF_U, i);
-        const double a = cyl ? fabs(B(C0_BA, i)) * (t == 0 ? 1.0 : sqrt(B(C0_Q, i))) : (half_line ? 0.0 : slab_a[t]);
+        double centre, a;
+        if (cyl) {
+          centre = B(C0_VZ, i);
+          a = fabs(B(C0_BA, i)) * (t == 0 ? 1.0 : sqrt(B(C0_Q, i)));
+        } else if (flow) {
+          centre = B(SF_U, i);
+          a = half_line ? 0.0 : slab_a[t];
+        } else {
+          const double c2 = B(SD_C2, i), vA2 = B(SD_VA2, i);
+          centre = 0.0;
+          a = sqrt(t == 0 ? c2 : (t == 1 ? c2 * vA2 / (c2 + vA2) : vA2));
+        }
+        if (a > 0.0 || half_line) never = false;
         const double lo = half_line ? -INFINITY : centre - a, hi = centre + a;
         if (!std::isfinite(hi) || (cyl && !(a > 0.0))) S.use_bands = 0;              // empty / undefined interval
         if (i > 0 && !half_line && a > 0.0 && !(lo < hi_prev && lo_prev < hi)) S.use_bands = 0;   // disjoint neighbours
@@ -477,8 +490,8 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
         lo_prev = lo; hi_prev = hi;
       }
       S.band[t][0] = lo_min; S.band[t][1] = lo_max; S.band[t][2] = hi_min; S.band[t][3] = hi_max;
-      // a speed of zero (e.g. cT_i = 0 without field): the term never changes sign -> band that nothing satisfies
-      if (!cyl && !half_line && !(slab_a[t] > 0.0)) { S.band[t][0] = INFINITY; S.band[t][3] = -INFINITY; }
+      // a speed of zero (e.g. cT = 0 without field): the term never changes sign -> a band that nothing satisfies
+      if (never) { S.band[t][0] = INFINITY; S.band[t][3] = -INFINITY; }
     }
     if (getenv("ES_FORCE_SIGN_TRACKING")) S.use_bands = 0;
   }

@@ -44,15 +44,16 @@ struct ShootDev {
   double slab_sign;   // -1 sausage: Vx(+1) = -Vx(-1);  +1 kink
   double c2_i, vA2_i, S_i, cT2_i, rho_i;   // uniform interior speeds of the flow slab
   int accept_norm;    // 0: rel uses max(|outer|,|inner|); 1: |outer| only (CR-KS:722)
-  // FAM_CYL0 / FAM_SLABF: continuum bands in phase speed, [term][min lo, max lo, min hi, max hi]
-  //   cylinder: term 0 Alfven, 1 cusp;  flow slab: 0 sound, 1 tube, 2 Alfven, 3 Doppler-shifted frequency (lo = -inf)
+  // FAM_CYL0 / FAM_SLABF / FAM_SLABD: continuum bands in phase speed, [term][min lo, max lo, min hi, max hi]
+  //   cylinder: term 0 Alfven, 1 cusp;  flow slab: 0 sound, 1 tube, 2 Alfven, 3 Doppler-shifted frequency (lo = -inf);
+  //   density slab: 0 sound, 1 tube, 2 Alfven (centred on W = 0)
   int use_bands, n_bands;
   double band[4][4];
 };
 
 template <int FAM> struct FamTraits;
 // families whose continuum flag can come from phase-speed bands (band_crossed) instead of per-node sign tracking
-template <int FAM> constexpr bool fam_has_bands() { return FAM == FAM_CYL0 || FAM == FAM_SLABF; }
+template <int FAM> constexpr bool fam_has_bands() { return FAM == FAM_CYL0 || FAM == FAM_SLABF || FAM == FAM_SLABD; }
 // SHAPE of A for the adjoint march: 0 off-diagonal (a11 = a22 = 0), 1 full, 2 companion (a11 = 0, a12 = 1)
 template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 7, SHAPE = 0; static constexpr bool DIAG = false; };
 template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 11, NE = 16, SHAPE = 1; static constexpr bool DIAG = true; };
@@ -157,12 +158,13 @@ struct SignTrack {
   }
 };
 
-// FAM_CYL0 / FAM_SLABF without per-node tracking (ShootDev::use_bands): omega_A^2 = k^2 bA^2 and the Doppler shift k v_z scale
+// FAM_CYL0 / FAM_SLABF / FAM_SLABD without per-node tracking (ShootDev::use_bands): omega_A^2 = k^2 bA^2 and the Doppler shift k v_z scale
 // with k, so  t1_j < 0  <=>  |W - vz_j| < |bA_j|  with W = omega/k, an interval (lo_j, hi_j) that does not depend on
 // k.  When consecutive intervals overlap (checked on the host at problem creation) their union is
 // (min lo, max hi) and  "negative at some node but not at all nodes"  <=>  W in (min lo, max hi) and not
 // (max lo < W < min hi): four comparisons per point instead of four integer ops per node.  Same for the cusp term
-// with |bA_j| sqrt(q_j), and for the flow slab with |W - U_j| < c_i, c_Ti, vA_i and W < U_j (lo = -infinity).
+// with |bA_j| sqrt(q_j), for the flow slab with |W - U_j| < c_i, c_Ti, vA_i and W < U_j (lo = -infinity), and for the
+// density slab with |W| < c_j, c_Tj, vA_j.
 __device__ __forceinline__ bool band_crossed(const ShootDev& P, double k, double w) {
   const double W = w / k;
   bool c = false;

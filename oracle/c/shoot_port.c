@@ -161,21 +161,34 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
   P->cT2_i = (P->S_i > 0.0) ? P->c2_i * P->vA2_i / P->S_i : 0.0;
   P->rho_i = d->rho_i;
   P->accept_norm = d->accept_norm;
-  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_SLAB_FLOW) {
+  if (d->geometry == ES_GEOM_CYLINDER || d->geometry == ES_GEOM_SLAB_FLOW || d->geometry == ES_GEOM_SLAB_DENSITY) {
     /* node j is inside band t of phase speed W iff centre_j - a_j < W < centre_j + a_j (cylinder: centre v_z, a = |bA|,
-       |bA| sqrt(q); flow slab: centre U, a = c_i, cT_i, vA_i, and the half line W < U_j); if consecutive node intervals
-       overlap, "inside at some node but not at all" is a test against four numbers */
-    const int cyl = (d->geometry == ES_GEOM_CYLINDER);
+       |bA| sqrt(q); flow slab: centre U, a = c_i, cT_i, vA_i, and the half line W < U_j; density slab: centre 0,
+       a = c_j, cT_j, vA_j); if consecutive node intervals overlap, "inside at some node but not at all" is a test
+       against four numbers */
+    const int cyl = (d->geometry == ES_GEOM_CYLINDER), flow = (d->geometry == ES_GEOM_SLAB_FLOW);
     P->use_bands = getenv("ES_FORCE_SIGN_TRACKING") ? 0 : 1;
-    P->n_bands = cyl ? 2 : 4;
+    P->n_bands = cyl ? 2 : (flow ? 4 : 3);
     const double slab_a[3] = {sqrt(P->c2_i), sqrt(P->cT2_i), sqrt(P->vA2_i)};
     for (int t = 0; t < P->n_bands; ++t) {
       double lo_min = INFINITY, lo_max = -INFINITY, hi_min = INFINITY, hi_max = -INFINITY, lo_prev = 0.0, hi_prev = 0.0;
-      const int half_line = (!cyl && t == 3);
+      const int half_line = (flow && t == 3);
+      int never = !cyl;
       for (int i = 0; i < npts; ++i) {
-        double centre = P->base[i], a;
-        if (cyl) { a = fabs(P->base[(size_t)1 * npts + i]); if (t == 1) a *= sqrt(P->base[(size_t)2 * npts + i]); }
-        else a = half_line ? 0.0 : slab_a[t];
+        double centre, a;
+        if (cyl) {
+          centre = P->base[i];
+          a = fabs(P->base[(size_t)1 * npts + i]);
+          if (t == 1) a *= sqrt(P->base[(size_t)2 * npts + i]);
+        } else if (flow) {
+          centre = P->base[i];
+          a = half_line ? 0.0 : slab_a[t];
+        } else {
+          double c2 = P->base[(size_t)1 * npts + i], vA2 = P->base[(size_t)2 * npts + i];
+          centre = 0.0;
+          a = sqrt(t == 0 ? c2 : (t == 1 ? c2 * vA2 / (c2 + vA2) : vA2));
+        }
+        if (a > 0.0 || half_line) never = 0;
         double lo = half_line ? -INFINITY : centre - a, hi = centre + a;
         if (!isfinite(hi) || (cyl && !(a > 0.0))) P->use_bands = 0;
         if (i > 0 && !half_line && a > 0.0 && !(lo < hi_prev && lo_prev < hi)) P->use_bands = 0;
@@ -183,7 +196,7 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
         lo_prev = lo; hi_prev = hi;
       }
       P->band[t][0] = lo_min; P->band[t][1] = lo_max; P->band[t][2] = hi_min; P->band[t][3] = hi_max;
-      if (!cyl && !half_line && !(slab_a[t] > 0.0)) { P->band[t][0] = INFINITY; P->band[t][3] = -INFINITY; }
+      if (never) { P->band[t][0] = INFINITY; P->band[t][3] = -INFINITY; }
     }
   }
   return P;
@@ -272,7 +285,7 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
     } break;
     case 2: {
       double w2 = w * w, n1 = e[0] - w2, n2 = e[1] - w2, n3 = e[2] - w2;
-      st_add(st, 0, n1); st_add(st, 1, n2); st_add(st, 2, n3);
+      if (st) { st_add(st, 0, n1); st_add(st, 1, n2); st_add(st, 2, n3); }
       C->n11 = 0.0; C->n22 = 0.0; C->n12 = n1; C->n21 = e[4] * n3; C->den = e[3] * n2;
     } break;
     default: {
@@ -409,7 +422,7 @@ int port_eval2(const port_problem* P, double k, double w, double w_cst, double* 
   coef B0, Bm, B1;
   /* adjoint march: one row of the transfer matrix, from the last node back to the boundary */
   make_entry(P, 2 * nsteps, &s, e);
-  strack* tp = ((P->family == 0 || P->family == 3) && P->use_bands) ? NULL : &trk;
+  strack* tp = (P->family != 1 && P->use_bands) ? NULL : &trk;
   coefficients(P, e, &s, w, &B0, tp);
   if (P->family <= 1 && P->axis_bc == ES_AXIS_SAUSAGE) { zp = B0.a11; zq = B0.a12; } else { zp = 1.0; zq = 0.0; }
   for (int j = nsteps - 1; j >= 0; --j) {

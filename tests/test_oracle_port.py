@@ -46,6 +46,7 @@ def test_continuum_bands_equal_per_node_tracking(monkeypatch):
     for eq, mode in [(q.CylinderFlow(U_i0=0.7, width=0.9), "kink"), (q.CylinderDensity(width=0.9), "sausage"),
                      (q.CylinderDensity(width=1.5, **photo), "kink"), (q.CylinderFlow(U_i0=-0.35, width=3.0), "sausage"),
                      (q.SlabFlow(U_i0=0.35, width=1.5), "kink"), (q.SlabFlow(U_i0=0.9, width=0.9), "sausage"),
+                     (q.SlabDensity(width=1.5, n_nodes=1001), "sausage"), (q.SlabDensity(width=0.9), "kink"),
                      (q.SlabFlow(c_i0=2.0 / 3.0, vA_i0=1.0, c_e=0.75, vA_e=0.0, U_i0=0.0, U_e=-0.15, width=float("inf"),
                                  L_factor=7.0), "kink")]:
         monkeypatch.delenv("ES_FORCE_SIGN_TRACKING", raising=False)

@@ -255,7 +255,7 @@ def test_continuum_bands_equal_per_node_tracking_gpu(es_ctx, monkeypatch):
     k = np.linspace(0.05, 4.0, 16)
     W = np.linspace(0.03, 5.0, 2048)
     for eq, mode in [(q.CylinderFlow(U_i0=0.7, width=0.9), "kink"), (q.CylinderDensity(width=0.9), "sausage"),
-                     (q.SlabFlow(U_i0=0.35, width=1.5), "kink")]:
+                     (q.SlabFlow(U_i0=0.35, width=1.5), "kink"), (q.SlabDensity(width=1.5), "sausage")]:
         monkeypatch.delenv("ES_FORCE_SIGN_TRACKING", raising=False)
         gb = ShootProblem(eq, mode, ctx=es_ctx)
         monkeypatch.setenv("ES_FORCE_SIGN_TRACKING", "1")
