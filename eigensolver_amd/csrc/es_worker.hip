@@ -20,9 +20,14 @@
 namespace {
 using namespace es_shoot_shared;
 
+// One activation of locate_*(): omega[3], loop index kk, itt_num.  The reference re-evaluates the two end points of
+// every refinement interval although it has just evaluated them (same inputs, same result); their mismatch, acceptance
+// measure and status are carried in the frame instead (cached = 1), so that only the mid-point costs an evaluation.
 struct Frame {
   double w0, w1, w2;
-  int kk, itt;
+  double d0, rel0, d2, rel2;
+  int kk, itt, cached;
+  uint8_t st0, st2;
 };
 
 struct WorkerArgs {
@@ -52,6 +57,9 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   double main_prev = 0.0, loop_prev = 0.0;           // *_diff_check[-1], *_diff_loop_check[-1] (start [0])
   int all_len = 0, loop_len = 0;                     // len(all_ws), len(loop_ws)
   double all_m1 = 0.0, all_m2 = 0.0, loop_m1 = 0.0, loop_m2 = 0.0;   // [-1], [-2]
+  // mismatch / measure / status at those points (for the end-point cache of the next refinement interval)
+  double all_d1 = 0.0, all_d2 = 0.0, all_r1 = 0.0, all_r2 = 0.0, loop_d1 = 0.0, loop_d2 = 0.0, loop_r1 = 0.0, loop_r2 = 0.0;
+  uint8_t all_s1 = 0, all_s2 = 0, loop_s1 = 0, loop_s2 = 0;
   double w_stale = 1.0;                              // grid frequency that opened the current refinement (CR-SF:617)
   bool done = !live;
   // hard bound on the work of one task (every loop iteration below consumes one evaluation or pops a frame)
@@ -60,6 +68,38 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   auto emit = [&](double w) {
     if (nroots < a.max_roots) a.roots[(size_t)t * a.max_roots + nroots] = w;
     ++nroots;
+  };
+
+  // one point of the loop inside locate_*() (CF:556-694), evaluated or taken from the frame's end-point cache; the
+  // frame's kk has already been advanced
+  auto loop_point = [&](double w, double d, double rel, uint8_t st) {
+    Frame& f = stk[sp - 1];
+    if ((long)nevals > eval_cap) { sp = 0; done = true; return; }
+    if (st == ES_PT_LEAKY) return;                              // `if m_e < 0: pass`
+    ++nevals;
+    loop_m2 = loop_m1; loop_m1 = w; ++loop_len;                 // loop_ws.append(omega[k])
+    loop_d2 = loop_d1; loop_d1 = d; loop_r2 = loop_r1; loop_r1 = rel; loop_s2 = loop_s1; loop_s1 = st;
+    const double sign = d * loop_prev;                          // CF:678
+    loop_prev = d;
+    if (rel < a.tol) {                                          // CF:681-686
+      emit(w);
+      loop_len = 0;
+      --sp;                                                     // break
+    } else if (sign < 0.0 && loop_len > a.min_len) {            // CF:688-694
+      const double lo = loop_m2, hi = loop_m1;
+      f.w0 = lo; f.w1 = lo + (hi - lo) * 0.5; f.w2 = hi;        // omega re-bound in the caller's frame
+      f.d0 = loop_d2; f.rel0 = loop_r2; f.st0 = loop_s2;        // both ends were evaluated inside locate_*()
+      f.d2 = loop_d1; f.rel2 = loop_r1; f.st2 = loop_s1;
+      f.cached = 1;
+      f.itt += 1;
+      loop_len = 0;
+      if (sp < a.stack_depth) {
+        Frame c = f;
+        c.kk = 0;
+        stk[sp] = c;
+        ++sp;
+      }
+    }
   };
 
   for (;;) {
@@ -78,6 +118,7 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
         if (st == ES_PT_LEAKY) continue;                          // `if m_e < 0: pass`
         ++nevals;
         all_m2 = all_m1; all_m1 = w; ++all_len;                   // all_ws.append(freq[j])
+        all_d2 = all_d1; all_d1 = d; all_r2 = all_r1; all_r1 = rel; all_s2 = all_s1; all_s1 = st;
         const double sign = d * main_prev;                        // sign_check.append(d * check[-2])
         main_prev = d;
         if (rel < a.tol) {                                        // CF:817
@@ -85,7 +126,10 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
           all_len = 0;
           if (a.break_on_accept) done = true;                     // CR-KF:722
         } else if (sign < 0.0 && all_len > a.min_len) {           // CF:822-829
-          Frame f{all_m2, all_m2 + (all_m1 - all_m2) * 0.5, all_m1, 0, 0};   // np.linspace(all_ws[-2], all_ws[-1], 3)
+          // np.linspace(all_ws[-2], all_ws[-1], 3); the end points keep their main-loop values unless the worker
+          // evaluates refinement points with a different exterior constant (CR-SF:617)
+          Frame f{all_m2, all_m2 + (all_m1 - all_m2) * 0.5, all_m1, all_d2, all_r2, all_d1, all_r1, 0, 0,
+                  a.stale_ext_const ? 0 : 1, all_s2, all_s1};
           all_len = 0;
           w_stale = w;
           stk[0] = f;
@@ -94,6 +138,12 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
       } else {                                                    // inside locate_*(): top frame
         Frame& f = stk[sp - 1];
         if (f.kk >= 3 || f.itt > a.itt_cap) { --sp; continue; }   // loop exhausted / `if itt_num > cap: break`
+        if (f.cached && f.kk != 1) {                              // end point: values known, no evaluation
+          const bool first = (f.kk == 0);
+          ++f.kk;
+          loop_point(first ? f.w0 : f.w2, first ? f.d0 : f.d2, first ? f.rel0 : f.rel2, first ? f.st0 : f.st2);
+          continue;
+        }
         w_eval = (f.kk == 0) ? f.w0 : (f.kk == 1 ? f.w1 : f.w2);
         need = true;
       }
@@ -103,30 +153,8 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
     double d, rel; uint8_t st;
     shoot_point<FAM>(P, k, w_eval, a.stale_ext_const ? w_stale : w_eval, d, rel, st, es_point_lds);
     if (need) {
-      Frame& f = stk[sp - 1];
-      ++f.kk;
-      if ((long)nevals > eval_cap) { sp = 0; done = true; }
-      else if (st != ES_PT_LEAKY) {
-        ++nevals;
-        loop_m2 = loop_m1; loop_m1 = w_eval; ++loop_len;          // loop_ws.append(omega[k])
-        const double sign = d * loop_prev;                        // CF:678
-        loop_prev = d;
-        if (rel < a.tol) {                                        // CF:681-686
-          emit(w_eval);
-          loop_len = 0;
-          --sp;                                                   // break
-        } else if (sign < 0.0 && loop_len > a.min_len) {          // CF:688-694
-          const double lo = loop_m2, hi = loop_m1;
-          f.w0 = lo; f.w1 = lo + (hi - lo) * 0.5; f.w2 = hi;      // omega re-bound in the caller's frame
-          f.itt += 1;
-          loop_len = 0;
-          if (sp < a.stack_depth) {
-            Frame c{f.w0, f.w1, f.w2, 0, f.itt};
-            stk[sp] = c;
-            ++sp;
-          }
-        }
-      }
+      ++stk[sp - 1].kk;
+      loop_point(w_eval, d, rel, st);
     }
   }
   if (live) {
