@@ -14,7 +14,16 @@
 // frames {omega[3], kk, itt}; after a child returns the parent continues its loop with the re-bound omega and the
 // incremented itt, as the Python code does.  All lanes of a wave call the determinant evaluation together (lanes
 // without a pending refinement point evaluate a dummy frequency), so the expensive part stays convergent.
+//
+// Phase B is a chain of dependent evaluations per task (refinement level after level), so a run with few tasks is
+// bound by the latency of one evaluation.  A task therefore owns L = 2^l lanes (l chosen on the host from the task
+// count): when the state machine needs the mid-point of an interval, the L lanes evaluate the whole binary tree of
+// mid-points l levels deep below that interval (lane i the node with heap index i + 1, formed with the same
+// lo + (hi - lo) * 0.5 the state machine uses, hence bit-identical frequencies) and keep the results; the next
+// l - 1 levels of the descent are then table look-ups (wave ballot on the frequency).  The L lanes of a task run the
+// state machine redundantly on identical state; results and decisions are exactly those of one lane per task.
 #include "es_shoot_shared.hpp"
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -34,6 +43,7 @@ struct WorkerArgs {
   double tol;
   int min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, stale_ext_const;
   int ntasks, nfreq, max_roots, stack_depth;
+  int log_lanes;                  // lanes per task = 1 << log_lanes (1 ... 64)
   const double* k;
   const double* freq;
   const double* D;
@@ -48,8 +58,26 @@ struct WorkerArgs {
 template <int FAM>
 __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   ES_POINT_LDS(FAM);
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int logL = a.log_lanes, L = 1 << logL;
+  const int grp = (int)threadIdx.x >> logL, sub = (int)threadIdx.x & (L - 1);
+  const int t = blockIdx.x * (64 >> logL) + grp;                  // all L lanes of a group serve task t
   const bool live = t < a.ntasks;
+  // this lane's entry of the group's speculation table
+  double tw = 0.0, td = 0.0, trel = 0.0;
+  int tst = 0;
+  bool tvalid = false;
+  // table look-up: is the frequency w held by a lane of this group?  (group-uniform control flow: the lanes of a
+  // group are always active together, so the ballot sees the whole group)
+  auto lookup = [&](double w, double& d, double& rel, uint8_t& st) -> bool {
+    const unsigned long long m = __ballot(tvalid && tw == w);
+    const unsigned long long gm = (L == 64) ? m : ((m >> (grp << logL)) & ((1ull << L) - 1ull));
+    if (gm == 0ull) return false;
+    const int src = (grp << logL) + (__ffsll((long long)gm) - 1);
+    d = __shfl(td, src);
+    rel = __shfl(trel, src);
+    st = (uint8_t)__shfl(tst, src);
+    return true;
+  };
   const double k = live ? a.k[t] : 1.0;
   Frame* stk = a.stack + (size_t)(live ? t : 0) * a.stack_depth;
   // per-task history (what the reference keeps in module-global lists)
@@ -104,8 +132,8 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
 
   for (;;) {
     // ---- advance without evaluating until a refinement point is needed --------------------------------------
-    bool need = false;
-    double w_eval = 1.0;
+    bool need = false, spec = false;
+    double w_eval = 1.0, root_lo = 0.0, root_hi = 0.0;
     while (!done && !need) {
       if (sp == 0) {                                              // main loop over freq (CF:702)
         if (j >= a.nfreq) { done = true; break; }
@@ -132,6 +160,7 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
                   a.stale_ext_const ? 0 : 1, all_s2, all_s1};
           all_len = 0;
           w_stale = w;
+          if (a.stale_ext_const) tvalid = false;                  // table entries depend on w_stale
           stk[0] = f;
           sp = 1;
         }
@@ -145,16 +174,44 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
           continue;
         }
         w_eval = (f.kk == 0) ? f.w0 : (f.kk == 1 ? f.w1 : f.w2);
+        {
+          double dl, rl; uint8_t sl;
+          if (lookup(w_eval, dl, rl, sl)) {                       // evaluated speculatively in an earlier round
+            ++f.kk;
+            loop_point(w_eval, dl, rl, sl);
+            continue;
+          }
+        }
+        spec = (f.kk == 1) && (L > 1);                            // mid-point: evaluate the tree below (w0, w2)
+        root_lo = f.w0; root_hi = f.w2;
         need = true;
       }
     }
     if (!__any(need)) break;                        // workgroup = one wave: the exit is workgroup-uniform
     // ---- one determinant evaluation per lane (dummy for lanes that do not need one) ---------------------------
+    double w_lane = w_eval;
+    if (need && spec) {
+      // node with heap index i = sub + 1 of the mid-point tree below (root_lo, root_hi); index L (last lane) is
+      // outside the tree and repeats the root
+      const int i = (sub + 1 < L) ? (sub + 1) : 1;
+      const int level = 31 - __clz(i);
+      double lo = root_lo, hi = root_hi;
+      for (int b = level - 1; b >= 0; --b) {
+        const double mid = lo + (hi - lo) * 0.5;
+        if ((i >> b) & 1) lo = mid; else hi = mid;
+      }
+      w_lane = lo + (hi - lo) * 0.5;
+    }
     double d, rel; uint8_t st;
-    shoot_point<FAM>(P, k, w_eval, a.stale_ext_const ? w_stale : w_eval, d, rel, st, es_point_lds);
+    shoot_point<FAM>(P, k, w_lane, a.stale_ext_const ? w_stale : w_lane, d, rel, st, es_point_lds);
     if (need) {
+      tw = w_lane; td = d; trel = rel; tst = st; tvalid = true;  // (re)build this group's table
+      // the point the state machine asked for: the root of the tree (lane 0 of the group) or every lane's own
+      const int src = (grp << logL);
+      const double d0 = __shfl(d, src), r0 = __shfl(rel, src);
+      const uint8_t s0 = (uint8_t)__shfl((int)st, src);
       ++stk[sp - 1].kk;
-      loop_point(w_eval, d, rel, st);
+      loop_point(w_eval, d0, r0, s0);
     }
   }
   if (live) {
@@ -165,7 +222,9 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
 
 template <int FAM>
 int launch_worker(es_context* ctx, const es_problem* prob, const WorkerArgs& a) {
-  hipLaunchKernelGGL((worker_kernel<FAM>), dim3((a.ntasks + 63) / 64), dim3(64), 0, ctx->stream, prob->dev, a);
+  const int tasks_per_wg = 64 >> a.log_lanes;
+  hipLaunchKernelGGL((worker_kernel<FAM>), dim3((a.ntasks + tasks_per_wg - 1) / tasks_per_wg), dim3(64), 0, ctx->stream,
+                     prob->dev, a);
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
@@ -202,6 +261,10 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
     a.reset_loop_ws_each_iter = spec->reset_loop_ws_each_iter; a.break_on_accept = spec->break_on_accept;
     a.stale_ext_const = spec->stale_ext_const;
     a.ntasks = ntasks; a.nfreq = nfreq; a.max_roots = max_roots; a.stack_depth = depth;
+    // lanes per task: as many as keep the launch within ~2 waves per SIMD (1024 SIMDs x 64 lanes x 2)
+    a.log_lanes = 6;
+    while (a.log_lanes > 0 && ((long)ntasks << a.log_lanes) > 131072L) --a.log_lanes;
+    if (const char* ev = getenv("ES_WORKER_LOG_LANES")) { const int v = atoi(ev); if (v >= 0 && v <= 6) a.log_lanes = v; }
     a.k = d_k; a.freq = d_freq; a.D = D; a.rel = rel; a.st = st; a.stack = stack;
     a.roots = d_roots; a.nroots = d_nroots; a.nevals = d_nevals;
     switch (prob->dev.family) {

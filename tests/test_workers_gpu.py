@@ -186,3 +186,33 @@ def test_driver_sweep_vs_reference_root_sets(es_ctx, name):
     # reference's own artefacts; most still agree
     assert n_dirty == 0 or same_dirty >= 0.5 * n_dirty, (name, same_dirty, n_dirty)
     solver.close()
+
+
+@pytest.mark.parametrize("log_lanes", [0, 1, 3, 6])
+def test_speculative_lanes_do_not_change_results(es_ctx, monkeypatch, log_lanes):
+    """A task may own 1 ... 64 lanes that evaluate the mid-point tree below a refinement interval ahead of the
+    state machine (ES_WORKER_LOG_LANES forces the count): the root lists and the number of evaluations the
+    reference would have performed are identical for every lane count, deep chains (p_tol = 1e-6) included."""
+    import eigensolver_amd as E
+    runs = [(E.SlabUniformFlow(ctx=es_ctx), np.linspace(0.2, 3.3, 24), None),
+            (E.CylinderNonUniformFlow(U_i0=0.6, width=1.0, ctx=es_ctx), np.linspace(0.05, 3.9, 20), 40),
+            (E.CylinderRotationalFlow(v_twist=0.15, power=1.25, variant="sausage", ctx=es_ctx), np.linspace(0.8, 3.9, 16), 40),
+            (E.SlabNonUniformDensity(width=1.5, ctx=es_ctx), np.linspace(0.3, 3.3, 8), 60)]
+    for s, ks, n in runs:
+        monkeypatch.setenv("ES_WORKER_LOG_LANES", "0")
+        ref = s.solve(ks, n) if n is not None else s.solve(ks)
+        monkeypatch.setenv("ES_WORKER_LOG_LANES", str(log_lanes))
+        out = s.solve(ks, n) if n is not None else s.solve(ks)
+        assert sum(len(v[0]) for v in ref.values()) > 0
+        for mode in ref:
+            assert np.array_equal(ref[mode][0], out[mode][0]) and np.array_equal(ref[mode][1], out[mode][1]), (type(s).__name__, mode)
+        # evaluation counts of one batch
+        mode = list(ref)[0]
+        k = float(ks[len(ks) // 2])
+        band = s.bands(k, n)[0] if n is not None else s.bands(k)[0]
+        monkeypatch.setenv("ES_WORKER_LOG_LANES", "0")
+        r0, e0 = s.run_batch(mode, [k], band[None, :], return_evals=True)
+        monkeypatch.setenv("ES_WORKER_LOG_LANES", str(log_lanes))
+        r1, e1 = s.run_batch(mode, [k], band[None, :], return_evals=True)
+        assert r0 == r1 and np.array_equal(e0, e1)
+        s.close()
