@@ -147,7 +147,11 @@ def test_driver_block_layout(es_ctx):
 ROOTSET_SOLVERS = {
     "CF_flow": ("CF_flow", "CF"), "CF_uniform": ("CF_uniform", "CF"), "CDC_w095": ("CDC_w095", "CD-C"),
     "SFG_flow": ("SFG_flow", "SF-G"), "CRKS": ("CRKS", "CR-KS"), "CRSF": ("CRSF", "CR-SF"),
+    "SDP_w15": ("SDP_w15", "SD-P"), "CDP": ("CDP", "CD-P"), "SFG_uniform": ("SFG_uniform", "SF-G"),
 }
+# sweeps that are only reported (tools/report_reference_agreement.py): in the checked-in CR-KF the reference's fsolve
+# fails (ier = 5) in most evaluations, so 4 of its 6 calls are artefacts; its 3 roots are all reproduced
+ROOTSET_REPORT_ONLY = {"CRKF": ("CRKF", "CR-KF")}
 
 
 @pytest.mark.parametrize("name", list(ROOTSET_SOLVERS))

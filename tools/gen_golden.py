@@ -199,6 +199,11 @@ ROOTSETS = {
                  [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.4, 2.45)], 40, ("kink", "sausage")),
     "CRKS": ("CR-KS", [], [0.6, 1.0, 1.5, 2.0, 3.0], [(0.7, 0.99), (1.21, 1.44)], 30, ("kink",)),
     "CRSF": ("CR-SF", [], [0.8, 1.2, 1.6, 2.0, 2.5, 3.0, 3.5], [(1.05, 1.4), (0.7, 0.99)], 30, ("sausage",)),
+    "SDP_w15": ("SD-P", [("1e5)  # inside slab x values", "2001)  # inside slab x values"), ("dx=1e5", "dx=1.5")],
+                [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(0.9, 1.25)], 30, ("kink", "sausage")),
+    "CDP": ("CD-P", [], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5], [(0.52, 1.48)], 30, ("kink", "sausage")),
+    "SFG_uniform": ("SF-G", [], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.05, 2.45)], 30, ("kink", "sausage")),
+    "CRKF": ("CR-KF", [], [0.6, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.21, 1.44)], 30, ("kink",)),
 }
 
 

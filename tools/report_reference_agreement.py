@@ -31,8 +31,8 @@ for name, (solver, key) in _solvers(ctx).items():
 print("total", tot)
 
 # larger driver-style sweeps
-from tests.test_workers_gpu import ROOTSET_SOLVERS  # noqa: E402
-for name, (skey, key) in ROOTSET_SOLVERS.items():
+from tests.test_workers_gpu import ROOTSET_REPORT_ONLY, ROOTSET_SOLVERS  # noqa: E402
+for name, (skey, key) in {**ROOTSET_SOLVERS, **ROOTSET_REPORT_ONLY}.items():
     path = os.path.join(G, f"roots_{name}.json")
     if not os.path.exists(path):
         continue
