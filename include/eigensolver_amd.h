@@ -199,7 +199,9 @@ typedef struct es_worker_spec {
 
 /* Task t: wavenumber d_k[t], frequencies d_freq[t*nfreq .. t*nfreq+nfreq).  Roots of task t are written to
  * d_roots[t*max_roots ...] in the order the reference appends them; d_nroots[t] is their number (may exceed
- * max_roots, then ES_ERR_CAPACITY is returned); d_nevals[t] (optional) counts determinant evaluations. */
+ * max_roots, then ES_ERR_CAPACITY is returned); d_nevals[t] (optional) counts the determinant evaluations the
+ * reference worker performs for the task (the library itself evaluates fewer points -- it does not re-evaluate the
+ * end points of a refinement interval -- and, with several lanes per task, some it never uses). */
 int es_worker_run(es_context* ctx, const es_problem* prob, const es_worker_spec* spec,
                   const double* d_k, int ntasks, const double* d_freq, int nfreq,
                   double* d_roots, int32_t* d_nroots, int max_roots, int32_t* d_nevals /* may be NULL */);
