@@ -273,3 +273,30 @@ def test_continuum_bands_equal_per_node_tracking_gpu(es_ctx, monkeypatch):
         assert np.array_equal(spb.cpu().numpy(), spt.cpu().numpy())
         gb.close()
         gt.close()
+
+
+@pytest.mark.parametrize("n_nodes", [2, 3, 4, 129, 130, 258, 1000])
+def test_node_count_extremes_cylinder(es_ctx, n_nodes):
+    """The paired-step march of the wide-row cylinder kernel (two RK4 steps per iteration, a single leading step in
+    chunks of odd length) and the one-point-per-lane kernels for step counts around the chunk size (128): both
+    against the CPU port, and against each other bit for bit."""
+    import dataclasses
+    from eigensolver_amd import ShootProblem, equilibrium as q
+    eq = dataclasses.replace(q.CylinderFlow(U_i0=0.7, width=0.9), n_nodes=n_nodes)
+    gp = ShootProblem(eq, "kink", ctx=es_ctx)
+    port = cases.port_problem(eq, "kink")
+    k = np.array([0.7, 1.9, 3.1])
+    W = 2.7 + (np.arange(2048) + 0.5) * (4.95 - 2.7) / 2048                    # >= 2048 columns: PTS = 4 variant
+    D, st, rel = gp.eval_grid(k, W, want_rel=True)
+    Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=8)
+    st, D = st.cpu().numpy(), D.cpu().numpy()
+    assert np.array_equal(st, stp)
+    ok = stp == 0
+    assert ok.sum() > 1000
+    sc = np.abs(Dp[ok]) * 100.0 / relp[ok]
+    assert (np.abs(D[ok] - Dp[ok]) / sc).max() < 1e-11
+    kk = np.repeat(k, 64)
+    ww = kk * np.tile(W[::32], 3)
+    Dq, sq = gp.eval_points(kk, ww)
+    assert np.array_equal(Dq.cpu().numpy().reshape(3, 64), D[:, ::32], equal_nan=True)
+    gp.close()
