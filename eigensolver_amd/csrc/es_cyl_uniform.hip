@@ -32,8 +32,8 @@ __device__ __forceinline__ double interior_logder(const UniDev& U, int m, double
   if (m_i > 0.0) {
     const double kap = sqrt(m_i), xa = kap * U.r_axis, xb = kap;
     double Ib, Ib1, Kb, Kb1, Ia, Ia1, Ka, Ka1;
-    esb::ie_pair(m, xb, Ib, Ib1);  esb::ke_pair(m, xb, Kb, Kb1);
-    esb::ie_pair(m, xa, Ia, Ia1);  esb::ke_pair(m, xa, Ka, Ka1);
+    esb::ke_pair(m, xb, Kb, Kb1);  esb::ie_pair_from_k(m, xb, Kb, Kb1, Ib, Ib1);
+    esb::ke_pair(m, xa, Ka, Ka1);  esb::ie_pair_from_k(m, xa, Ka, Ka1, Ia, Ia1);
     const double dIb = Ib1 + (dm / xb) * Ib, dKb = -Kb1 + (dm / xb) * Kb;      // scaled derivatives
     const double dIa = Ia1 + (dm / xa) * Ia, dKa = -Ka1 + (dm / xa) * Ka;
     // P = I + beta K ; in scaled form beta K(xb)/I(xb) carries exp(-2 (xb - xa))
