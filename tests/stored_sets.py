@@ -12,8 +12,10 @@ A stored root (k, omega) must satisfy the acceptance measure rel = 100|d|/max(|o
 (tol = the worker's own p_tol / xi_tol).  Pooled over a family the measures the port computes for the stored roots
 fill [0, tol) and stop sharply at tol (e.g. cylinder flow kink: 386 roots in [0.75, 1) tol, 1 in [1, 1.25) tol), which
 pins the oracle's measure to the reference's to about a percent (test_acceptance_measure_cutoff).  Exception: the
-rotational sausage_fast files, whose refined roots were accepted with the stale exterior constant of CR-SF:617 that a
-pointwise re-evaluation cannot know; their measures tail off smoothly above 1.5.  FLOORS (golden/stored_roots_floors.json, written by
+rotational sausage_fast files: their roots are points of a 40-per-band main grid accepted at tol = 1.5 %, which is the
+size of the error of the reference's own LSODA exterior solve (up to 2e-2 of the scale: it starts at P = 1e-8, below
+its absolute tolerance), so the reference's measure scatters around the oracle's by about a tolerance and the cutoff
+is smeared.  FLOORS (golden/stored_roots_floors.json, written by
 tests/stored_roots_survey.py) holds the minimum accepted fraction per file and mode; files listed in UNPINNED are
 carried as data but not asserted, with the reason."""
 import json
