@@ -16,6 +16,9 @@ struct es_context {
   int* d_block_counts = nullptr;   size_t blocks_cap = 0;     // per-256-cell block counts / exclusive offsets
   int* d_total = nullptr;                                     // device-side total count
   int* h_total = nullptr;                                     // pinned host mirror
+  // general call scratch (worker tables and frame stacks, refinement start data): grown on demand, never shrunk;
+  // calls on one context are serialised by its stream, so one buffer suffices
+  void* d_scratch = nullptr;       size_t scratch_cap = 0;
 };
 
 #define ES_HIP_CHECK(ctx, expr)                                                                 \
@@ -34,6 +37,9 @@ struct es_context {
       return ES_ERR_INVALID_ARG;                                                                \
     }                                                                                           \
   } while (0)
+
+// Grow ctx->d_scratch to at least `bytes` (synchronises the stream before freeing the old buffer).
+int es_ensure_scratch(es_context* ctx, size_t bytes);
 
 // Grow the compaction scratch so that `cells` cells fit.
 int es_ensure_scan_scratch(es_context* ctx, size_t cells);

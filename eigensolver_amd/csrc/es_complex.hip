@@ -364,17 +364,15 @@ extern "C" int es_complex_find_roots(es_context* ctx, const es_problem* prob, in
   *out_count = total;
   const int n = total < table->capacity ? total : table->capacity;
   if (n > 0) {
-    double* half = nullptr;
-    ES_HIP_CHECK(ctx, hipMalloc(&half, 2 * (size_t)n * sizeof(double)));
+    rc = es_ensure_scratch(ctx, 2 * (size_t)n * sizeof(double));
+    if (rc) return rc;
+    double* half = (double*)ctx->d_scratch;
     hipLaunchKernelGGL(cx_emit_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w_re, d_w_im, n_re, n_im,
                        w_mode, cells, ctx->d_masks, ctx->d_block_counts, *table, half, half + n);
     hipLaunchKernelGGL(cx_refine_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, prob->dev, variant, *table,
                        half, half + n, n, n_iter, tol_percent);
-    const hipError_t e1 = hipGetLastError();
-    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(half);
-    ES_HIP_CHECK(ctx, e1);
-    ES_HIP_CHECK(ctx, e2);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return (total > table->capacity) ? ES_ERR_CAPACITY : ES_SUCCESS;
 }

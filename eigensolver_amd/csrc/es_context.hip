@@ -49,6 +49,7 @@ extern "C" int es_context_destroy(es_context* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->d_masks) (void)hipFree(ctx->d_masks);
   if (ctx->d_block_counts) (void)hipFree(ctx->d_block_counts);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_total) (void)hipFree(ctx->d_total);
   if (ctx->h_total) (void)hipHostFree(ctx->h_total);
   delete ctx;
@@ -60,6 +61,21 @@ extern "C" const char* es_last_error(const es_context* ctx) { return ctx ? ctx->
 extern "C" int es_context_synchronize(es_context* ctx) {
   if (!ctx) return ES_ERR_INVALID_ARG;
   ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ES_SUCCESS;
+}
+
+int es_ensure_scratch(es_context* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_cap) return ES_SUCCESS;
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ctx->d_scratch) {
+    ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));        // earlier calls may still read the old buffer
+    ES_HIP_CHECK(ctx, hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_cap = 0;
+  }
+  const size_t cap = bytes + bytes / 4;                          // head room: batches of a sweep grow slowly
+  ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, cap));
+  ctx->scratch_cap = cap;
   return ES_SUCCESS;
 }
 

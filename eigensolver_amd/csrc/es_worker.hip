@@ -243,16 +243,16 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t cells = (size_t)ntasks * (size_t)(nfreq > 0 ? nfreq : 1);
   const int depth = spec->itt_cap + 3;
-  double *D = nullptr, *rel = nullptr;
-  uint8_t* st = nullptr;
-  Frame* stack = nullptr;
-  int rc = ES_SUCCESS;
-  // scratch of one call (not on the benchmark path): main-loop table + frame stacks
-  if (hipMalloc(&D, cells * sizeof(double)) != hipSuccess || hipMalloc(&rel, cells * sizeof(double)) != hipSuccess ||
-      hipMalloc(&st, cells) != hipSuccess || hipMalloc(&stack, (size_t)ntasks * depth * sizeof(Frame)) != hipSuccess) {
-    ctx->last_error = "hipMalloc(worker scratch) failed";
-    rc = ES_ERR_HIP;
-  }
+  // scratch of one call, carved out of the context's buffer: main-loop table (D, rel, status) + frame stacks
+  auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t bD = align(cells * sizeof(double)), bS = align(cells), bF = align((size_t)ntasks * depth * sizeof(Frame));
+  int rc = es_ensure_scratch(ctx, 2 * bD + bS + bF);
+  if (rc) return rc;
+  char* base = (char*)ctx->d_scratch;
+  double* D = (double*)base;
+  double* rel = (double*)(base + bD);
+  Frame* stack = (Frame*)(base + 2 * bD);
+  uint8_t* st = (uint8_t*)(base + 2 * bD + bF);
   if (rc == ES_SUCCESS && nfreq > 0)
     rc = es_shoot_eval_grid(ctx, prob, d_k, ntasks, d_freq, nfreq, ES_W_PER_ROW, D, rel, st);
   if (rc == ES_SUCCESS) {
@@ -279,10 +279,6 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
     ctx->last_error = "worker kernel failed";
     rc = ES_ERR_HIP;
   }
-  if (D) (void)hipFree(D);
-  if (rel) (void)hipFree(rel);
-  if (st) (void)hipFree(st);
-  if (stack) (void)hipFree(stack);
   if (rc != ES_SUCCESS) return rc;
   // capacity check on the host (counts are small)
   std::vector<int32_t> h((size_t)ntasks);
