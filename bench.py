@@ -39,7 +39,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 # algorithmic traffic per det-eval of the grid kernel: 8 B D + 1 B status written, inputs amortised
 BYTES_PER_EVAL = 8.0 + 1.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-FLOPS_PER_STEP = 2 * 11 + 6 + 32            # 2 coefficient sets (1 add, 2 fma, 2 mul, 2 fma each) + shared reciprocal (1 div + 5 mul) + one adjoint RK4 step (32)
+FLOPS_PER_STEP = 2 * 9 + 8 + 32             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step (32)
 
 
 def workload_equilibrium():

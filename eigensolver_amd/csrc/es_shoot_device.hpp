@@ -92,12 +92,14 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
     e[1] = wA2;                                // omega_A^2
     e[2] = wA2 * b[C0_Q];                      // omega_c^2 = omega_A^2 c^2/(c^2+vA^2)
     e[3] = b[C0_A1];                           // rho / r
-    // -r C2/(rho S) = g t2 - B (t2 + omega_c^2)^2 with t2 = Om^2 - omega_c^2, B = r/(rho S),
-    // g = (m^2/r^2 + k^2) r/rho:  Horner coefficients in t2
+    // a21 = -r C2/(rho S t1 t2) with -r C2/(rho S) = g t2 - B (t2 + omega_c^2)^2, B = r/(rho S),
+    // g = (m^2/r^2 + k^2) r/rho, t1 = t2 + omega_c^2 - omega_A^2.  Dividing the quadratic by t1 t2:
+    //     a21 = -B + (lambda t2 + c0) / (t1 t2),   lambda = g - B (omega_A^2 + omega_c^2),   c0 = -B omega_c^4
+    // so the numerator left over the denominator is LINEAR in t2 (one fma) and -B joins in the fma with 1/den.
     const double Bq = b[C0_B1];
     const double g = s.m2 * b[C0_E1] + s.k2 * b[C0_E2];
     e[4] = -Bq;
-    e[5] = g - 2.0 * (Bq * e[2]);
+    e[5] = g - Bq * (e[1] + e[2]);
     e[6] = -(Bq * (e[2] * e[2]));
   } else if (FAM == FAM_CYLT) {
     const double r = b[CT_R], invr = b[CT_INVR], rho = b[CT_RHO], S = b[CT_S];
@@ -190,9 +192,10 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     const double t1 = fma(Om, Om, -e[1]);                // Om^2 - omega_A^2
     const double t2 = fma(Om, Om, -e[2]);                // Om^2 - omega_c^2
     if (TRACK) { st.add(0, t1); st.add(1, t2); }
-    C.n11 = 0.0; C.n22 = 0.0;
+    C.n11 = 0.0;
     C.n12 = e[3] * t1;                                   // rho (Om^2 - wA^2) / r
-    C.n21 = fma(fma(e[4], t2, e[5]), t2, e[6]);          // -r C2 / (rho S)            /den
+    C.n21 = fma(e[5], t2, e[6]);                         // lambda t2 + c0              /den
+    C.n22 = e[4];                                        // -B, added after the division (coef_finish)
     C.den = t1 * t2;
   } else if (FAM == FAM_CYLT) {
     const double Om = w - e[0];
@@ -248,7 +251,7 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
 template <int FAM>
 __device__ __forceinline__ void coef_finish(const CoefPre& C, double inv, Coef& A) {
   if (FAM == FAM_CYL0) {
-    A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12; A.a21 = C.n21 * inv;
+    A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12; A.a21 = fma(C.n21, inv, C.n22);
   } else if (FAM == FAM_CYLT) {
     A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
   } else if (FAM == FAM_SLABD) {

@@ -235,8 +235,8 @@ static void make_entry(const port_problem* P, int pt, const kscal* s, double* e)
       double wA = s->k * b[1], wA2 = wA * wA;
       double g = s->m2 * b[5] + s->k2 * b[6];
       e[0] = s->k * b[0]; e[1] = wA2; e[2] = wA2 * b[2]; e[3] = b[3];
-      /* -r C2/(rho S) = g t2 - B (t2 + wc^2)^2, t2 = Om^2 - wc^2: Horner coefficients in t2 */
-      e[4] = -b[4]; e[5] = g - 2.0 * (b[4] * e[2]); e[6] = -(b[4] * (e[2] * e[2]));
+      /* a21 = -r C2/(rho S t1 t2) = -B + (lambda t2 + c0)/(t1 t2), lambda = g - B (wA^2 + wc^2), c0 = -B wc^4 */
+      e[4] = -b[4]; e[5] = g - b[4] * (e[1] + e[2]); e[6] = -(b[4] * (e[2] * e[2]));
     } break;
     case 1: {
       double r = b[0], invr = b[1], rho = b[2], S = b[3];
@@ -265,9 +265,10 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
     case 0: {
       double Om = w - e[0], t1 = fma(Om, Om, -e[1]), t2 = fma(Om, Om, -e[2]);
       if (st) { st_add(st, 0, t1); st_add(st, 1, t2); }
-      C->n11 = 0.0; C->n22 = 0.0;
+      C->n11 = 0.0;
       C->n12 = e[3] * t1;
-      C->n21 = fma(fma(e[4], t2, e[5]), t2, e[6]);
+      C->n21 = fma(e[5], t2, e[6]);
+      C->n22 = e[4];
       C->den = t1 * t2;
     } break;
     case 1: {
@@ -304,7 +305,7 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
 
 static void coef_finish(const port_problem* P, const coefpre* C, double inv, coef* A) {
   switch (P->family) {
-    case 0: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12; A->a21 = C->n21 * inv; break;
+    case 0: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12; A->a21 = fma(C->n21, inv, C->n22); break;
     case 1: A->a11 = C->n11 * inv; A->a22 = C->n22 * inv; A->a12 = C->n12 * inv; A->a21 = C->n21 * inv; break;
     case 2: A->a11 = 0.0; A->a22 = 0.0; A->a12 = C->n12 * inv; A->a21 = C->n21; break;
     default: A->a11 = 0.0; A->a12 = 1.0; A->a21 = C->n21 * inv; A->a22 = C->n22 * inv;
