@@ -273,7 +273,8 @@ __device__ __forceinline__ void coefficients(const double* e, const ShootDev& P,
 // Reciprocal for the hot loop: hardware seed r0 (v_rcp_f64, relative error e ~ 2^-23 at worst) and ONE third-order
 // correction  r = r0 (1 + e + e^2),  e = 1 - x r0  (exact to fma rounding):  1/x = r0/(1 - e), so the truncation error
 // is e^3 < 2^-69 and the result is the correctly rounded r0 + r0 (e + e^2) up to the last bit -- within 1 ulp of the
-// IEEE quotient 1.0/x (identical to it for all but a few arguments in a million), at 4 instructions instead of the
+// IEEE quotient 1.0/x (measured, tools/probe/rcp_probe.hip: seed error 2^-24.4, result identical to the IEEE quotient
+// for all of 4.2e6 random arguments; one Newton step alone leaves 2.2e-15), at 4 instructions instead of the
 // 11 of the IEEE division sequence (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup) or 5 with two Newton
 // steps.  Zero / non-finite denominators give non-finite results either way (flagged lanes).
 __device__ __forceinline__ double fast_rcp(double x) {
