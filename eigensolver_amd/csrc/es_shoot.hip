@@ -23,8 +23,9 @@ namespace {
 using namespace es_shoot_shared;
 
 // ------------------------------------------------------------------------------------------------------------
-template <int FAM, int PTS, int MAXT, bool TRACK>
-__global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
+template <int FAM, int PTS, int MAXT, bool TRACK, int WPE = 0>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
+void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
                                                           const double* __restrict__ wv, int nw, int w_mode,
                                                           double* __restrict__ Dout, double* __restrict__ relout,
                                                           uint8_t* __restrict__ stout) {
@@ -32,6 +33,10 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
   constexpr int LSTRIDE = 2 * CH + 1;
   // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
   constexpr bool PAIR = (FAM == FAM_CYL0) && (PTS == 4) && !TRACK;
+  // register-capped instantiations (WPE != 0) park the exterior results in LDS during the march instead of letting
+  // the compiler spill them to scratch (HBM): 4 doubles per point, lane-contiguous (conflict-free)
+  constexpr bool STASH = (WPE != 0);
+  __shared__ double xstash[STASH ? 4 * PTS * MAXT : 1];
   __shared__ double lds[NE * LSTRIDE];
   const int T = blockDim.x;
   const int nsteps = P.n_nodes - 1;
@@ -53,18 +58,22 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
       }
       // exterior closed form first: here only w[] is live, so the ~100 VGPRs of the Bessel code overlap with nothing
       // and only its three results per point are carried through the march (no call frame, no scratch)
-      ExteriorLite X[PTS];
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) X[p] = exterior_lite(P, k, w[p], w[p]);
       // a wave none of whose points has an evanescent exterior (leaky / non-finite: D is NaN whatever the march gives)
       // only takes part in the LDS staging and the barriers
+      ExteriorLite X[PTS];
       bool lane_live = false;
 #pragma unroll
       for (int p = 0; p < PTS; ++p) {
+        X[p] = exterior_lite(P, k, w[p], w[p]);
         lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK);
-        zp[p] = 0.0; zq[p] = 0.0;
+        if (STASH) {                                   // parked at once: not live during the next Bessel evaluation
+          double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;
+          xs[0] = X[p].outer; xs[MAXT] = X[p].yb; xs[2 * MAXT] = X[p].Oe; xs[3 * MAXT] = (double)X[p].status;
+        }
       }
       const bool wave_live = __any(lane_live);
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) { zp[p] = 0.0; zq[p] = 0.0; }
       // adjoint march: chunks from the far end of the interior back to the boundary
       const int nchunks = (nsteps + CH - 1) / CH;
       for (int c = nchunks - 1; c >= 0; --c) {
@@ -126,6 +135,13 @@ __global__ __launch_bounds__(MAXT) void shoot_grid_kernel(ShootDev P, const doub
           }
         }
 #undef ES_MARCH_STEP
+      }
+      if (STASH) {
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) {
+          const double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;
+          X[p].outer = xs[0]; X[p].yb = xs[MAXT]; X[p].Oe = xs[2 * MAXT]; X[p].status = (int)xs[3 * MAXT];
+        }
       }
       // boundary: exterior closed form + far-end condition + mismatch
       double bf[FamTraits<FAM>::NB], ef[NE];
@@ -284,14 +300,19 @@ int check_problem(es_context* ctx, const es_problem* prob) {
 //   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)
 //   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD, no scratch)  -- default for rows >= 2048 wide
 //   variant 2: PTS = 1, up to 1024 threads                                         -- narrow rows (worker batches)
-// Variant 1 is the fastest on wide rows (FAM_CYL0, 4096^2: 26.2 ms against 27.6 / 30.0 ms for variants 0 / 2): four
-// independent points per lane cover the fp64 dependency chains and share the broadcast LDS reads.
+//   variant 3: PTS = 4, up to  256 threads, registers capped at 168 (amdgpu_waves_per_eu 3): three workgroups per
+//              CU = 3 waves/SIMD; the spills this costs sit in the exterior, outside the march.  Default for the
+//              untwisted cylinder on rows >= 2048 wide (4096^2: 24.0 ms against 25.2 ms for variant 1); the other
+//              families need more registers per point and lose (twisted cylinder: 14.3 ms against 7.9 ms at 1024^2).
+// Four points per lane (variants 1, 3) are the fastest on wide rows (FAM_CYL0, 4096^2: 26.2 ms against 27.6 / 30.0 ms
+// for variants 0 / 2 at the time of r1e): independent points cover the fp64 dependency chains and share the
+// broadcast LDS reads.
 // ES_GRID_VARIANT in the environment overrides the default (tuning aid).
 template <int FAM>
 int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
                 int w_mode, double* d_D, double* d_rel, uint8_t* d_status) {
   const int grid = nk < 65535 ? nk : 65535;
-  int variant = (nw >= 2048) ? 1 : ((nw >= 1024) ? 0 : 2);
+  int variant = (nw >= 2048) ? ((FAM == FAM_CYL0) ? 3 : 1) : ((nw >= 1024) ? 0 : 2);
   if (const char* ev = getenv("ES_GRID_VARIANT")) variant = atoi(ev);
   auto roundT = [](int pts_needed, int maxT) {
     int T = (pts_needed + 63) / 64 * 64;
@@ -301,16 +322,23 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   };
   // families with connected continuum bands: no per-node sign tracking (band_crossed)
   const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
-#define ES_LAUNCH_GRID(PTS, MAXT, T)                                                                                \
+#define ES_LAUNCH_GRID_W(PTS, MAXT, T, WPE)                                                                         \
   do {                                                                                                              \
     if (bands)                                                                                                      \
-      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, !fam_has_bands<FAM>()>), dim3(grid), dim3(T), 0,        \
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, !fam_has_bands<FAM>(), WPE>), dim3(grid), dim3(T), 0,   \
                          ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                   \
     else                                                                                                            \
-      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, true>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, \
-                         d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                           \
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, true, WPE>), dim3(grid), dim3(T), 0, ctx->stream,       \
+                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                \
   } while (0)
-  if (variant == 1) {
+#define ES_LAUNCH_GRID(PTS, MAXT, T) ES_LAUNCH_GRID_W(PTS, MAXT, T, 0)
+  if (variant == 3 && FAM != FAM_CYL0) variant = 1;          // the register-capped shape exists for FAM_CYL0 only
+  if (variant == 3) {
+    if constexpr (FAM == FAM_CYL0) {
+      const int T = roundT((nw + 3) / 4, 256);
+      ES_LAUNCH_GRID_W(4, 256, T, 3);
+    }
+  } else if (variant == 1) {
     const int T = roundT((nw + 3) / 4, 512);
     ES_LAUNCH_GRID(4, 512, T);
   } else if (variant == 0) {
@@ -321,6 +349,7 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
     ES_LAUNCH_GRID(1, 1024, T);
   }
 #undef ES_LAUNCH_GRID
+#undef ES_LAUNCH_GRID_W
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
