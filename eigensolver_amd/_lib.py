@@ -37,6 +37,15 @@ def load():
     return _lib
 
 
+def load_variant(path):
+    """A second build of the library (tests only: lib/libeigensolver_amd_ieee.so, -DES_IEEE_DIVISION) with the same
+    signatures; ctypes keeps the symbols of each handle apart."""
+    import torch  # noqa: F401
+    if not os.path.exists(path):
+        raise EsError(f"{path} not found: build it with `python -m eigensolver_amd.build`")
+    return _sig(C.CDLL(path))
+
+
 def check(ctx, status, allow_capacity=False):
     if status == 0 or (allow_capacity and status == 3):
         return status
@@ -49,11 +58,11 @@ def check(ctx, status, allow_capacity=False):
 class Context:
     """Owns an es_context bound to a HIP device and (optionally) a torch stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, lib=None):
         import torch
         if not torch.cuda.is_available():
             raise EsError("no HIP device visible: eigensolver_amd has no CPU path")
-        self.lib = load()
+        self.lib = lib if lib is not None else load()
         self.device = int(device)
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
@@ -112,7 +121,7 @@ class RootTable(C.Structure):
 class WorkerSpec(C.Structure):
     _fields_ = [("tol_percent", C.c_double), ("min_len", C.c_int32), ("itt_cap", C.c_int32),
                 ("reset_loop_ws_each_iter", C.c_int32), ("break_on_accept", C.c_int32),
-                ("stale_ext_const", C.c_int32), ("reserved", C.c_int32)]
+                ("stale_ext_const", C.c_int32), ("main_double_append", C.c_int32)]
 
 
 class CylUniformParams(C.Structure):

@@ -15,6 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libeigensolver_amd.so")
+# test-only variant compiled with -DES_IEEE_DIVISION: every reciprocal of the hot loops is the IEEE quotient the CPU port
+# computes, so the interior march is bit-identical to oracle/c/shoot_port.c (tests/test_shoot_gpu.py); never loaded by
+# the product path
+LIB_IEEE = os.path.join(LIBDIR, "libeigensolver_amd_ieee.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -37,23 +41,20 @@ def _deps():
     return out
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(s) > t for s in _deps())
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+def _compile_and_link(lib, extra_flags, tag, verbose):
     hipcc = _hipcc()
     objs = []
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + tag + ".o")
+        cmd = [hipcc] + FLAGS + extra_flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -64,10 +65,19 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed for {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    return lib
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or needs_build(LIB):
+        _compile_and_link(LIB, [], "", verbose)
+    if force or needs_build(LIB_IEEE):
+        _compile_and_link(LIB_IEEE, ["-DES_IEEE_DIVISION"], ".ieee", verbose)
     return LIB
 
 

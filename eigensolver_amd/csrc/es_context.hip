@@ -24,6 +24,7 @@ extern "C" const char* es_status_string(int s) {
     case ES_ERR_CAPACITY: return "output capacity too small";
     case ES_ERR_NO_DEVICE: return "no HIP device";
     case ES_ERR_UNSUPPORTED: return "unsupported configuration";
+    case ES_ERR_EVAL_CAP: return "worker task exceeded its evaluation cap";
     default: return "unknown status";
   }
 }

@@ -42,10 +42,17 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
   const int nsteps = P.n_nodes - 1;
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
 
-  for (int row = blockIdx.x; row < nk; row += gridDim.x) {
+  // tile = (k-row, omega-segment of T*PTS points): rows wider than one segment are split across workgroups, so the
+  // number of workgroups is nk * nseg (narrow k-tiles of a multi-GPU run still fill the chip, and the tail of the
+  // launch is one segment long instead of one row)
+  const int nseg = (nw + T * PTS - 1) / (T * PTS);
+  const long ntiles = (long)nk * nseg;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row = (int)(tile / nseg);
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
-    for (int w0 = 0; w0 < nw; w0 += T * PTS) {
+    {
+      const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
       double w[PTS], zp[PTS], zq[PTS];
       Coef B0[PTS], B1[PTS];
       SignTrack trk[PTS];
@@ -72,10 +79,12 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
         }
       }
       const bool wave_live = __any(lane_live);
+      // a workgroup without any evanescent point (a whole omega-segment of leaky / singular points) skips the march
+      const bool wg_live = __syncthreads_or(wave_live ? 1 : 0) != 0;
 #pragma unroll
       for (int p = 0; p < PTS; ++p) { zp[p] = 0.0; zq[p] = 0.0; }
       // adjoint march: chunks from the far end of the interior back to the boundary
-      const int nchunks = (nsteps + CH - 1) / CH;
+      const int nchunks = wg_live ? (nsteps + CH - 1) / CH : 0;
       for (int c = nchunks - 1; c >= 0; --c) {
         const int c0 = c * CH;
         const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
@@ -311,7 +320,6 @@ int check_problem(es_context* ctx, const es_problem* prob) {
 template <int FAM>
 int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
                 int w_mode, double* d_D, double* d_rel, uint8_t* d_status) {
-  const int grid = nk < 65535 ? nk : 65535;
   int variant = (nw >= 2048) ? ((FAM == FAM_CYL0) ? 3 : 1) : ((nw >= 1024) ? 0 : 2);
   if (const char* ev = getenv("ES_GRID_VARIANT")) variant = atoi(ev);
   auto roundT = [](int pts_needed, int maxT) {
@@ -324,6 +332,8 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
 #define ES_LAUNCH_GRID_W(PTS, MAXT, T, WPE)                                                                         \
   do {                                                                                                              \
+    const long tiles_ = (long)nk * ((nw + (T) * (PTS) - 1) / ((T) * (PTS)));                                        \
+    const int grid = (int)(tiles_ < (1L << 22) ? tiles_ : (1L << 22));                                              \
     if (bands)                                                                                                      \
       hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, !fam_has_bands<FAM>(), WPE>), dim3(grid), dim3(T), 0,   \
                          ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                   \

@@ -41,7 +41,7 @@ struct Frame {
 
 struct WorkerArgs {
   double tol;
-  int min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, stale_ext_const;
+  int min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, stale_ext_const, main_double_append;
   int ntasks, nfreq, max_roots, stack_depth;
   int log_lanes;                  // lanes per task = 1 << log_lanes (1 ... 64)
   const double* k;
@@ -53,6 +53,8 @@ struct WorkerArgs {
   double* roots;
   int32_t* nroots;
   int32_t* nevals;
+  long eval_cap;                  // hard bound on the evaluations of one task
+  int* abort_flag;                // set to 1 by any task that hit eval_cap (its root list is incomplete)
 };
 
 template <int FAM>
@@ -89,9 +91,10 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   double all_d1 = 0.0, all_d2 = 0.0, all_r1 = 0.0, all_r2 = 0.0, loop_d1 = 0.0, loop_d2 = 0.0, loop_r1 = 0.0, loop_r2 = 0.0;
   uint8_t all_s1 = 0, all_s2 = 0, loop_s1 = 0, loop_s2 = 0;
   double w_stale = 1.0;                              // grid frequency that opened the current refinement (CR-SF:617)
-  bool done = !live;
-  // hard bound on the work of one task (every loop iteration below consumes one evaluation or pops a frame)
-  const long eval_cap = 3L * (a.itt_cap + 2) * (a.nfreq + 1);
+  bool done = !live, aborted = false;
+  // hard bound on the work of one task (every loop iteration below consumes one evaluation or pops a frame); a task
+  // that reaches it is reported (negative nevals, ES_ERR_EVAL_CAP from es_worker_run), never silently truncated
+  const long eval_cap = a.eval_cap;
 
   auto emit = [&](double w) {
     if (nroots < a.max_roots) a.roots[(size_t)t * a.max_roots + nroots] = w;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   // frame's kk has already been advanced
   auto loop_point = [&](double w, double d, double rel, uint8_t st) {
     Frame& f = stk[sp - 1];
-    if ((long)nevals > eval_cap) { sp = 0; done = true; return; }
+    if ((long)nevals > eval_cap) { sp = 0; done = true; aborted = true; return; }
     if (st == ES_PT_LEAKY) return;                              // `if m_e < 0: pass`
     ++nevals;
     loop_m2 = loop_m1; loop_m1 = w; ++loop_len;                 // loop_ws.append(omega[k])
@@ -147,6 +150,10 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
         ++nevals;
         all_m2 = all_m1; all_m1 = w; ++all_len;                   // all_ws.append(freq[j])
         all_d2 = all_d1; all_d1 = d; all_r2 = all_r1; all_r1 = rel; all_s2 = all_s1; all_s1 = st;
+        if (a.main_double_append) {                               // ... and once more (CR-SF:684 and :726)
+          all_m2 = w; ++all_len;
+          all_d2 = d; all_r2 = rel; all_s2 = st;
+        }
         const double sign = d * main_prev;                        // sign_check.append(d * check[-2])
         main_prev = d;
         if (rel < a.tol) {                                        // CF:817
@@ -216,7 +223,8 @@ __global__ __launch_bounds__(64) void worker_kernel(ShootDev P, WorkerArgs a) {
   }
   if (live) {
     a.nroots[t] = nroots;
-    if (a.nevals) a.nevals[t] = nevals;
+    if (a.nevals) a.nevals[t] = aborted ? -nevals : nevals;
+    if (aborted && sub == 0) atomicOr(a.abort_flag, 1);
   }
 }
 
@@ -260,6 +268,7 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
     a.tol = spec->tol_percent; a.min_len = spec->min_len; a.itt_cap = spec->itt_cap;
     a.reset_loop_ws_each_iter = spec->reset_loop_ws_each_iter; a.break_on_accept = spec->break_on_accept;
     a.stale_ext_const = spec->stale_ext_const;
+    a.main_double_append = spec->main_double_append;
     a.ntasks = ntasks; a.nfreq = nfreq; a.max_roots = max_roots; a.stack_depth = depth;
     // lanes per task: as many as keep the launch within ~2 waves per SIMD (1024 SIMDs x 64 lanes x 2)
     a.log_lanes = 6;
@@ -267,6 +276,11 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
     if (const char* ev = getenv("ES_WORKER_LOG_LANES")) { const int v = atoi(ev); if (v >= 0 && v <= 6) a.log_lanes = v; }
     a.k = d_k; a.freq = d_freq; a.D = D; a.rel = rel; a.st = st; a.stack = stack;
     a.roots = d_roots; a.nroots = d_nroots; a.nevals = d_nevals;
+    a.eval_cap = 3L * (spec->itt_cap + 2) * ((long)nfreq + 1);
+    if (const char* ev = getenv("ES_WORKER_EVAL_CAP")) { const long v = atol(ev); if (v > 0) a.eval_cap = v; }   // test aid
+    a.abort_flag = ctx->d_total;
+    if (hipMemsetAsync(ctx->d_total, 0, sizeof(int), ctx->stream) != hipSuccess) rc = ES_ERR_HIP;
+    if (rc == ES_SUCCESS)
     switch (prob->dev.family) {
       case FAM_CYL0: rc = launch_worker<FAM_CYL0>(ctx, prob, a); break;
       case FAM_CYLT: rc = launch_worker<FAM_CYLT>(ctx, prob, a); break;
@@ -280,6 +294,11 @@ extern "C" int es_worker_run(es_context* ctx, const es_problem* prob, const es_w
     rc = ES_ERR_HIP;
   }
   if (rc != ES_SUCCESS) return rc;
+  ES_HIP_CHECK(ctx, hipMemcpy(ctx->h_total, ctx->d_total, sizeof(int), hipMemcpyDeviceToHost));
+  if (*ctx->h_total != 0) {
+    ctx->last_error = "a worker task exceeded its evaluation cap (root list incomplete; d_nevals < 0 marks the task)";
+    return ES_ERR_EVAL_CAP;
+  }
   // capacity check on the host (counts are small)
   std::vector<int32_t> h((size_t)ntasks);
   ES_HIP_CHECK(ctx, hipMemcpy(h.data(), d_nroots, (size_t)ntasks * sizeof(int32_t), hipMemcpyDeviceToHost));

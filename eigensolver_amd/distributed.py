@@ -60,6 +60,61 @@ def gather_root_tables(roots, m, world=None, group=None):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0).to(home)
 
 
+# ---- fixed-capacity exchange: ONE collective per step, no host synchronisation -------------------------------------
+# Record layout of the k-tiled grid search: (k, omega, m, resid, flag, global row).  Every rank sends a buffer of
+# cap + 1 rows whose row 0 carries its bracket count, so counts and records travel in the same all-gather and nothing
+# has to be read back on the host before the collective is enqueued (the two-phase exchange above needs the counts on
+# the host first).  Ranks whose count exceeds `cap` are detected when the gathered buffer is merged.
+N_FIELDS = 6
+
+
+def pack_fixed(roots, count, m, rows_global, cap):
+    """(cap + 1, 6) send buffer on the device of `roots`; rows_global[i] = global k-row of local row i (tensor)."""
+    import torch
+    dev = roots["w"].device
+    send = torch.zeros((cap + 1, N_FIELDS), dtype=torch.float64, device=dev)
+    n = min(int(count), cap, roots["w"].numel())
+    send[0, 0] = float(count)
+    if n > 0:
+        send[1:n + 1, 0] = roots["k"][:n]
+        send[1:n + 1, 1] = roots["w"][:n]
+        send[1:n + 1, 2] = float(m)
+        send[1:n + 1, 3] = roots["resid"][:n]
+        send[1:n + 1, 4] = roots["flag"][:n].to(torch.float64)
+        send[1:n + 1, 5] = rows_global[roots["row"][:n].long()].to(torch.float64)
+    return send
+
+
+def gather_fixed(send, world=None, group=None):
+    """One all-gather of the fixed-size buffers -> (world, cap + 1, 6) on every rank (device of `send`; through host
+    memory for gloo ranks that share a GPU)."""
+    import torch
+    import torch.distributed as dist
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return send.unsqueeze(0)
+    home = send.device
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        send = send.cpu()
+    out = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(out, send, group=group)          # concatenation along dim 0, rank-major
+    return out.view(world, send.shape[0], send.shape[1]).to(home)
+
+
+def merge_fixed(buf):
+    """Gathered buffers -> (records sorted by (global row, position within the rank's table), counts per rank).  With
+    k-rows tiled across ranks this is exactly the single-GPU table order (rows outer, omega inner).  Host side."""
+    b = buf.detach().cpu().numpy()
+    cap = b.shape[1] - 1
+    counts = [int(round(b[r, 0, 0])) for r in range(b.shape[0])]
+    if max(counts) > cap:
+        raise OverflowError(f"root table of a rank has {max(counts)} records, exchange capacity {cap}")
+    rec = np.concatenate([b[r, 1:1 + c] for r, c in enumerate(counts)], axis=0) if sum(counts) else np.zeros((0, N_FIELDS))
+    order = np.argsort(rec[:, 5], kind="stable")
+    return rec[order], counts
+
+
 def gather_mode_results(local, group=None):
     """All-gather per-mode (omega, k) arrays of a k-tiled driver run: local = {"sausage": (w, k), "kink": (w, k)}
     (NumPy) -> the concatenation over ranks (rank-major) on every rank.  Same exchange pattern as

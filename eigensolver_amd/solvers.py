@@ -29,14 +29,21 @@ from .shooting import ShootProblem
 class _WorkerSolver:
     """Common machinery: problems per mode, batched worker runs, the reference-signature entry points."""
 
-    # (tol_percent, min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, accept_norm[, stale_ext_const]) per mode
+    # (tol_percent, min_len, itt_cap, reset_loop_ws_each_iter, break_on_accept, accept_norm[, stale_ext_const
+    #  [, main_double_append]]) per mode
     WORKER = {}
     modes = ("sausage", "kink")
 
     def __init__(self, eq, ctx=None):
         self.eq = eq
-        self.ctx = ctx if ctx is not None else _lib.Context()
+        self._ctx = ctx                 # created on first GPU use: speeds() / bands() / eq need no device
         self._problems = {}
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.Context()
+        return self._ctx
 
     def close(self):
         for p in self._problems.values():
@@ -52,7 +59,8 @@ class _WorkerSolver:
     def worker_spec(self, mode, tol=None):
         t = self.WORKER[mode]
         stale = int(t[6]) if len(t) > 6 else 0
-        return _lib.WorkerSpec(float(t[0] if tol is None else tol), int(t[1]), int(t[2]), int(t[3]), int(t[4]), stale, 0)
+        dbl = int(t[7]) if len(t) > 7 else 0
+        return _lib.WorkerSpec(float(t[0] if tol is None else tol), int(t[1]), int(t[2]), int(t[3]), int(t[4]), stale, dbl)
 
     def run_batch(self, mode, wavenumbers, freqs, tol=None, max_roots=None, return_evals=False):
         """Many worker calls at once: wavenumbers[t], freqs[t, :] -> list of root lists (one per task)."""
@@ -174,8 +182,9 @@ class CylinderRotationalFlow(_WorkerSolver):
     def __init__(self, v_twist=0.25, power=0.8, variant="kink_fast", ctx=None, **kw):
         spec = {"kink_fast": ("kink", (2.5, 2, 500, 0, 1, 0), 1e-3),        # CR-KF:435, :464, :722
                 "kink_slow": ("kink", (3.0, 2, 500, 0, 1, 1), 1e-3),        # CR-KS:441, :468, :722
-                "sausage": ("sausage", (1.5, 2, 250, 0, 0, 0, 1), 1e-2),    # CR-SF:419, :475, r_ax 0.01 (:157), stale xi_e_const (:558)
-                "sausage_slow": ("sausage", (4.5, 2, 250, 0, 0, 0, 1), 1e-2)}[variant]
+                # CR-SF:419, :475, r_ax 0.01 (:157), stale xi_e_const (:558), all_ws appended twice (:684, :726)
+                "sausage": ("sausage", (1.5, 2, 250, 0, 0, 0, 1, 1), 1e-2),
+                "sausage_slow": ("sausage", (4.5, 2, 250, 0, 0, 0, 1, 1), 1e-2)}[variant]           # CR-SS:423, :479
         self.modes = (spec[0],)
         self.WORKER = {spec[0]: spec[1]}
         self.variant = variant
@@ -204,6 +213,12 @@ class SlabNonUniformDensity(_WorkerSolver):
 
     def speeds(self):
         e = self.eq
+        if self.coronal:
+            # SD-C:202: speeds = [1.0, cT_bound, 1.2, 1.3, 0.9], cT_bound = tube speed of the profile at x = -1 (SD-C:182-185)
+            pr = eqm.SlabDensity(**{**e.__dict__, "n_nodes": 2}).profiles()        # points -1, 0, +1
+            c2b, vA2b = float(pr["c2"][0]), float(pr["vA2"][0])
+            cT_bound = float(np.sqrt(c2b * vA2b / (c2b + vA2b)))
+            return [1.0, cT_bound, 1.2, 1.3, 0.9]
         return [e.c_i0, e.cT_i0]                                                                  # SD-P:171 (zoom speeds, uniform case)
 
 

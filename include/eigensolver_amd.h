@@ -31,7 +31,8 @@ enum {
   ES_ERR_HIP = 2,          /* a HIP runtime call failed: see es_last_error()           */
   ES_ERR_CAPACITY = 3,     /* caller-provided output buffer too small (count is still returned) */
   ES_ERR_NO_DEVICE = 4,
-  ES_ERR_UNSUPPORTED = 5
+  ES_ERR_UNSUPPORTED = 5,
+  ES_ERR_EVAL_CAP = 6      /* es_worker_run: a task exceeded its evaluation bound; its root list is incomplete   */
 };
 
 /* ---- per-point status written next to D(k, omega) ------------------------------------------------------
@@ -194,12 +195,17 @@ typedef struct es_worker_spec {
   int32_t break_on_accept;         /* CR kink workers: `break` after the first accepted grid point (CR-KF:722) */
   int32_t stale_ext_const;         /* CR sausage workers: locate_sausage() uses the enclosing loop's xi_e_const, i.e. the
                                       value at the grid frequency that opened the bracket (CR-SF:558 vs :617)            */
-  int32_t reserved;
+  int32_t main_double_append;      /* CR sausage workers append freq[j] to all_ws twice per main-loop evaluation (CR-SF:684 and
+                                      :726): len(all_ws) > 2 holds after two evaluations and the refinement interval
+                                      linspace(all_ws[-2], all_ws[-1], 3) is the degenerate [w, w, w]                     */
 } es_worker_spec;
 
 /* Task t: wavenumber d_k[t], frequencies d_freq[t*nfreq .. t*nfreq+nfreq).  Roots of task t are written to
  * d_roots[t*max_roots ...] in the order the reference appends them; d_nroots[t] is their number (may exceed
- * max_roots, then ES_ERR_CAPACITY is returned); d_nevals[t] (optional) counts the determinant evaluations the
+ * max_roots, then ES_ERR_CAPACITY is returned).  Every task is bounded by 3 (itt_cap + 2)(nfreq + 1) evaluations (the
+ * reference bounds the recursion by itt_cap only); a task that reaches the bound stops, is marked by a NEGATIVE
+ * d_nevals[t] and makes the call return ES_ERR_EVAL_CAP -- its root list is incomplete, never silently truncated.
+ * d_nevals[t] (optional) counts the determinant evaluations the
  * reference worker performs for the task (the library itself evaluates fewer points -- it does not re-evaluate the
  * end points of a refinement interval -- and, with several lanes per task, some it never uses). */
 int es_worker_run(es_context* ctx, const es_problem* prob, const es_worker_spec* spec,

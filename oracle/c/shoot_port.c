@@ -410,7 +410,26 @@ static exterior ext_slab(const port_problem* P, double k, double w) {
  * exterior constant xi_e_const is taken (= w except inside CR-SF's locate_sausage, see oracle/workers.py). */
 int port_eval2(const port_problem* P, double k, double w, double w_cst, double* D, double* rel);
 int port_eval(const port_problem* P, double k, double w, double* D, double* rel) { return port_eval2(P, k, w, w, D, rel); }
+static int port_eval_core(const port_problem* P, double k, double w, double w_cst, const double* ext_override,
+                          double* D, double* rel, double* outer_out, double* inner_out);
 int port_eval2(const port_problem* P, double k, double w, double w_cst, double* D, double* rel) {
+  return port_eval_core(P, k, w, w_cst, NULL, D, rel, NULL, NULL);
+}
+/* The same evaluation with the exterior END STATE (value, slope at the boundary) supplied by the caller instead of
+ * the closed form -- used by tests/test_reference_agreement.py to feed the reference's own LSODA exterior end state
+ * (golden fixtures) to this interior, which separates the reference's exterior error from its interior noise.
+ * Also returns outer / inner (xi_e, xi_i resp. P_e, P_i, normalised by |value|). */
+int port_eval_ext(const port_problem* P, double k, double w, double w_cst, double ext_value, double ext_slope,
+                  double* D, double* rel, double* outer, double* inner) {
+  const double ov[2] = {ext_value, ext_slope};
+  return port_eval_core(P, k, w, w_cst, ov, D, rel, outer, inner);
+}
+int port_eval_parts(const port_problem* P, double k, double w, double w_cst, double* D, double* rel, double* outer,
+                    double* inner) {
+  return port_eval_core(P, k, w, w_cst, NULL, D, rel, outer, inner);
+}
+static int port_eval_core(const port_problem* P, double k, double w, double w_cst, const double* ext_override,
+                          double* D, double* rel, double* outer_out, double* inner_out) {
   kscal s;
   s.k = k; s.k2 = k * k; s.m = (double)P->m; s.m2 = s.m * s.m;
   s.kc2 = s.k2 * P->c2_i; s.kvA2 = s.k2 * P->vA2_i; s.kcT2 = s.k2 * P->cT2_i;
@@ -434,6 +453,10 @@ int port_eval2(const port_problem* P, double k, double w, double w_cst, double* 
     B0 = B1;
   }
   exterior X = (P->family <= 1) ? ext_cyl(P, k, w, w_cst) : ext_slab(P, k, w);
+  if (ext_override && X.status == ES_PT_OK) {
+    const double nrm = fabs(ext_override[0]);
+    X.yb = ext_override[0] / nrm; X.dyb = ext_override[1] / nrm;
+  }
   double outer, inner;
   if (P->family <= 1) {
     double Pb = X.yb, xi_e = X.cst * X.dyb, Xb;
@@ -458,6 +481,8 @@ int port_eval2(const port_problem* P, double k, double w, double w_cst, double* 
   double sc = P->accept_norm ? fabs(outer) : fmax(fabs(outer), fabs(inner));
   *D = d;
   *rel = fabs(d) * 100.0 / sc;
+  if (outer_out) *outer_out = outer;
+  if (inner_out) *inner_out = inner;
   if (X.status != ES_PT_OK) { *D = NAN; *rel = NAN; return st; }
   if (!isfinite(d)) return ES_PT_NONFINITE;
   if (tp ? st_crossed(&trk) : band_crossed(P, k, w)) st = ES_PT_CONTINUUM;

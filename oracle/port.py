@@ -44,6 +44,8 @@ def lib():
         L.port_destroy.argtypes = [vp]
         L.port_eval.argtypes = [vp, d, d, C.POINTER(d), C.POINTER(d)]
         L.port_eval2.argtypes = [vp, d, d, d, C.POINTER(d), C.POINTER(d)]
+        L.port_eval_ext.argtypes = [vp, d, d, d, d, d, C.POINTER(d), C.POINTER(d), C.POINTER(d), C.POINTER(d)]
+        L.port_eval_parts.argtypes = [vp, d, d, d, C.POINTER(d), C.POINTER(d), C.POINTER(d), C.POINTER(d)]
         L.port_eval_points.argtypes = [vp, vp, vp, l, vp, vp, vp, i]
         L.port_eval_grid.argtypes = [vp, vp, i, vp, i, i, vp, vp, vp, i]
         L.port_find_roots.restype = l
@@ -75,6 +77,17 @@ class PortProblem:
             lib().port_destroy(self.h)
         except Exception:
             pass
+
+    def eval_one(self, k, w, w_cst=None, ext=None):
+        """One evaluation -> (status, d, rel, outer, inner); ext = (value, slope): exterior end state override."""
+        D, rel, outer, inner = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        wc = w if w_cst is None else w_cst
+        if ext is None:
+            st = lib().port_eval_parts(self.h, k, w, wc, C.byref(D), C.byref(rel), C.byref(outer), C.byref(inner))
+        else:
+            st = lib().port_eval_ext(self.h, k, w, wc, float(ext[0]), float(ext[1]), C.byref(D), C.byref(rel),
+                                     C.byref(outer), C.byref(inner))
+        return st, D.value, rel.value, outer.value, inner.value
 
     def eval_points(self, k, w, nthreads=0):
         k = np.ascontiguousarray(k, dtype=np.float64).ravel()

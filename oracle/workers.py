@@ -42,6 +42,10 @@ class WorkerSpec:
     break_on_accept: bool = False           # CR kink workers: break the main loop at the first accepted grid point
     accept_norm_outer_only: bool = False    # CR-KS:722 divides by |xi_e| instead of max(|xi_e|, |xi_i|)
     stale_ext_const: bool = False           # CR-SF/SS: locate_sausage reads the enclosing loop's xi_e_const (CR-SF:558 vs :617)
+    main_double_append: bool = False        # CR-SF/SS: the main loop appends freq[j] to all_ws TWICE per evaluation
+                                            # (CR-SF:684 and :726; CR-SS:688, :730), so len(all_ws) > 2 holds after two
+                                            # evaluations and linspace(all_ws[-2], all_ws[-1], 3) is the degenerate
+                                            # interval [w, w, w]: these workers never narrow a bracket
 
 
 # the checked-in values of every worker (file:line of tolerance / cap)
@@ -59,8 +63,8 @@ SPECS = {
     ("CF", "kink"): WorkerSpec(6.0, 2, 250), ("CF", "sausage"): WorkerSpec(6.0, 2, 250),       # CF:530, :566
     ("CR-KF", "kink"): WorkerSpec(2.5, 2, 500, break_on_accept=True),                 # CR-KF:435, :464
     ("CR-KS", "kink"): WorkerSpec(3.0, 2, 500, break_on_accept=True, accept_norm_outer_only=True),  # CR-KS:441, :722
-    ("CR-SF", "sausage"): WorkerSpec(1.5, 2, 250, stale_ext_const=True),              # CR-SF:419, :475, :558
-    ("CR-SS", "sausage"): WorkerSpec(4.5, 2, 250, stale_ext_const=True),              # CR-SS:423, :479, :562
+    ("CR-SF", "sausage"): WorkerSpec(1.5, 2, 250, stale_ext_const=True, main_double_append=True),   # CR-SF:419, :475, :558, :684/:726
+    ("CR-SS", "sausage"): WorkerSpec(4.5, 2, 250, stale_ext_const=True, main_double_append=True),   # CR-SS:423, :479, :562, :688/:730
 }
 
 
@@ -80,6 +84,16 @@ class WorkerRun:
         self.all_ws = []
         self.loop_ws = []
         self.w_stale = None
+        # one record per evaluated point, in order: what was evaluated and what the worker decided there
+        # (tests/agreement.py compares two runs decision by decision)
+        self.log = []
+        self._last_idx = {"main": None, "loop": None}
+
+    def _record(self, where, w, st, d, outer, inner, prev, accepted, refined):
+        self.log.append({"where": where, "w": float(w), "st": int(st), "d": d, "outer": outer, "inner": inner,
+                         "prev": prev, "prev_idx": self._last_idx[where], "accepted": bool(accepted),
+                         "refined": bool(refined), "w_cst": self.w_stale if where == "loop" else None})
+        self._last_idx[where] = len(self.log) - 1
 
     def _accepts(self, d, outer, inner):
         s = self.spec
@@ -107,13 +121,17 @@ class WorkerRun:
             if st == ST_LEAKY:
                 continue
             self.loop_ws.append(omega[kk])
+            prev = self.loop_prev
             sign = d * self.loop_prev
             self.loop_prev = d
-            if self._accepts(d, outer, inner):
+            acc = self._accepts(d, outer, inner)
+            ref = (not acc) and sign < 0 and len(self.loop_ws) > s.min_len
+            self._record("loop", omega[kk], st, d, outer, inner, prev, acc, ref)
+            if acc:
                 self.roots.append(omega[kk])
                 self.loop_ws = []
                 break
-            elif sign < 0 and len(self.loop_ws) > s.min_len:
+            elif ref:
                 omega = list(np.linspace(self.loop_ws[-2], self.loop_ws[-1], 3))
                 itt = itt + 1
                 self.loop_ws = []
@@ -128,14 +146,20 @@ class WorkerRun:
             if st == ST_LEAKY:
                 continue
             self.all_ws.append(float(w))
+            if s.main_double_append:
+                self.all_ws.append(float(w))
+            prev = self.main_prev
             sign = d * self.main_prev
             self.main_prev = d
-            if self._accepts(d, outer, inner):
+            acc = self._accepts(d, outer, inner)
+            ref = (not acc) and sign < 0 and len(self.all_ws) > s.min_len
+            self._record("main", w, st, d, outer, inner, prev, acc, ref)
+            if acc:
                 self.roots.append(float(w))
                 self.all_ws = []
                 if s.break_on_accept:
                     break
-            elif sign < 0 and len(self.all_ws) > s.min_len:
+            elif ref:
                 omega = np.linspace(self.all_ws[-2], self.all_ws[-1], 3)
                 self.all_ws = []
                 self.w_stale = float(w)

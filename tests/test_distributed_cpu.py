@@ -97,3 +97,79 @@ def test_gather_mode_results_gloo_world2():
     assert got[0]["sausage"][1] == [0.0] * 5 + [1.0] * 2 and got[0]["kink"][1] == [1.0] * 7
     exp0 = np.random.default_rng(0).random(5).tolist()
     assert got[0]["sausage"][0][:5] == exp0
+
+
+# ---- strong scaling: ONE (k, omega) grid, k-rows tiled over the ranks (bench.py default mode) -----------------------
+def _grid_problem():
+    """Small version of the bench workload with the oracle's C port as the compute stand-in (no GPU here): the tiling,
+    the fixed-capacity exchange and the merge are the code bench.py runs over RCCL."""
+    from eigensolver_amd import equilibrium as q, shooting as s
+    from oracle.port import PortProblem
+    eq = q.CylinderFlow(U_i0=0.7, width=0.9, n_nodes=200)
+    d, prof = s.make_desc(eq, "kink", 1)
+    port = PortProblem({f[0]: getattr(d, f[0]) for f in d._fields_}, prof)
+    k = np.linspace(0.2, 3.9, 21)
+    W = 0.9 + (np.arange(64) + 0.5) * (4.1 / 64)
+    return port, k, W
+
+
+def _tile_step(port, k, W, rows):
+    Dg, rel, st = port.eval_grid(k[rows], W, w_mode=1, nthreads=1)
+    r, cnt = port.find_roots(k[rows], W, Dg, st, w_mode=1, n_bisect=16, tol=1e-3, nthreads=1)
+    roots = {n: torch.as_tensor(np.ascontiguousarray(r[n])) for n in ("k", "w", "resid", "flag", "row")}
+    return roots, cnt
+
+
+def _worker_tiled(rank, world, port_no, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port_no)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    port, k, W = _grid_problem()
+    rows = D.tile_rows(len(k), rank, world, strided=True)
+    roots, cnt = _tile_step(port, k, W, rows)
+    buf = D.gather_fixed(D.pack_fixed(roots, cnt, 1, torch.as_tensor(rows), cap), world)
+    try:
+        rec, counts = D.merge_fixed(buf)
+        q.put((rank, rec, counts))
+    except OverflowError as e:
+        q.put((rank, str(e), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_tiled(world, cap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_no = _free_port()
+    procs = [ctx.Process(target=_worker_tiled, args=(r, world, port_no, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, rec, counts = q.get(timeout=300)
+        got[r] = (rec, counts)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_k_tiled_grid_root_set_equals_single_rank():
+    """The gathered root table of an N-rank k-tiled run is the N = 1 table, record for record (same order: k-rows
+    outer, omega inner), on every rank -- world sizes 2 and 3 (ragged tiles: 21 rows)."""
+    port, k, W = _grid_problem()
+    roots, cnt = _tile_step(port, k, W, np.arange(len(k)))
+    single = D.merge_fixed(D.gather_fixed(D.pack_fixed(roots, cnt, 1, torch.arange(len(k)), 256), 1))[0]
+    assert single.shape == (cnt, D.N_FIELDS) and cnt > 10
+    assert np.all(np.diff(single[:, 5]) >= 0)
+    for world in (2, 3):
+        got = _run_tiled(world, 256)
+        for r in range(world):
+            rec, counts = got[r]
+            assert sum(counts) == cnt
+            assert np.array_equal(rec, single), (world, r)
+
+
+def test_fixed_exchange_reports_overflow():
+    got = _run_tiled(2, 4)                 # capacity far below the number of brackets of a tile
+    assert all(isinstance(got[r][0], str) and "capacity" in got[r][0] for r in range(2))

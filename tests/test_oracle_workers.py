@@ -13,7 +13,8 @@ from tests.test_oracle_golden import PROBLEMS, G
 
 FILE_KEY = {"CF_uniform": "CF", "CF_flow": "CF", "CDC_w095": "CD-C", "CDC_uniform": "CD-C", "CDP": "CD-P",
             "CRSF": "CR-SF", "CRKS": "CR-KS", "CRKF": "CR-KF", "SFU": "SF-U", "SFG_uniform": "SF-G",
-            "SFG_flow": "SF-G", "SDP_uniform": "SD-P", "SDP_w15": "SD-P"}
+            "SFG_flow": "SF-G", "SDP_uniform": "SD-P", "SDP_w15": "SD-P", "SDC_w09": "SD-C", "SDC_uniform": "SD-C",
+            "CRSS": "CR-SS"}
 
 
 def _replay_evaluator(prob, call):
@@ -47,7 +48,7 @@ def test_replay_reference_trace(case):
         spec = W.SPECS[(FILE_KEY[case], call["fn"])]
         # the tolerance in the trace is the one the reference ran with
         tol = tr.get("xi_tol") if call["fn"] == "kink" and "xi_tol" in tr else tr.get("p_tol", tr.get("P_tol"))
-        if FILE_KEY[case].startswith(("CD", "CF")) or FILE_KEY[case] in ("CR-SF", "CR-SS"):
+        if FILE_KEY[case].startswith(("CD-", "CF")) or FILE_KEY[case] in ("CR-SF", "CR-SS"):
             tol = tr["xi_tol"]               # both cylinder workers test against xi_tol (CD-C:809, :1106)
         assert tol == spec.tol, (case, tol, spec.tol)
         prob = PROBLEMS[case](call["fn"])

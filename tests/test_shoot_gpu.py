@@ -36,13 +36,75 @@ def test_grid_vs_port(es_ctx, name):
     scale = np.abs(Dp[ok]) * 100.0 / relp[ok]                 # max(|outer|, |inner|)
     err = np.abs(D[ok] - Dp[ok]) / scale
     assert err.max() < D_RTOL, (name, err.max())
-    # determinant signs bit-exact wherever D is not within rounding of zero
-    big = np.abs(Dp[ok]) > 1e-9 * scale
-    assert np.array_equal(np.signbit(D[ok][big]), np.signbit(Dp[ok][big]))
+    # determinant signs: every point is compared and reported; a sign may differ only where BOTH values are within the
+    # documented GPU-vs-port rounding (D_RTOL of the scale) of zero -- no exclusion zone beyond that bound
+    diff = np.signbit(D[ok]) != np.signbit(Dp[ok])
+    near0 = np.abs(Dp[ok]) <= 1e-9 * scale
+    print(f"{name}: {ok.sum()} points, {near0.sum()} with |D| <= 1e-9 scale, {diff.sum()} sign differences, "
+          f"max |dD|/scale {err.max():.2e}")
+    assert np.all(np.abs(Dp[ok][diff]) <= D_RTOL * scale[diff]) and np.all(np.abs(D[ok][diff]) <= D_RTOL * scale[diff])
     assert np.allclose(rel[ok], relp[ok], rtol=1e-9, atol=1e-12)
     # flagged lanes carry NaN where the reference skips the point
     assert np.all(np.isnan(D[(st == 1) | (st == 2)]))
     gp.close()
+
+
+@pytest.fixture(scope="module")
+def ieee_ctx():
+    """Context on the test-only build with -DES_IEEE_DIVISION (lib/libeigensolver_amd_ieee.so): every reciprocal of the
+    hot loops is the IEEE quotient, as in the CPU port."""
+    from eigensolver_amd import _lib, build
+    ctx = _lib.Context(0, lib=_lib.load_variant(build.LIB_IEEE))
+    yield ctx
+    ctx.close()
+
+
+def _ulps(a, b):
+    """Distance in units in the last place between two finite float64 arrays of the same sign."""
+    ia, ib = a.view(np.int64), b.view(np.int64)
+    return np.abs(ia - ib)
+
+
+@pytest.mark.parametrize("name", ["SD_w15_kink", "SD_w15_sausage", "CF_flow_kink", "CF_flow_sausage", "CDC_w095_kink",
+                                  "CF_flow_m3"])
+def test_ieee_division_build_is_bitwise_the_port(ieee_ctx, es_ctx, name):
+    """With IEEE divisions the GPU and the CPU port run the same operations in the same order on the same inputs: the
+    only difference left is exp / log of two math libraries in the closed-form EXTERIOR (<= 1 ulp each).
+      * density slab (FAM_SLABD): the exterior's exp() only enters through a term below 1e-16 of the value, so D is
+        BITWISE the port's at every evaluated point;
+      * untwisted cylinder (FAM_CYL0): the Bessel exterior carries exp / log roundings, D within a few ulps of the
+        scale, bitwise at most points -- the interior march itself is identical.
+    The default build differs from this one only through fast_rcp / qdiv (<= 1 ulp of each reciprocal): asserted below
+    as |D_default - D_ieee| <= 1e-12 of the scale and identical statuses."""
+    from eigensolver_amd import ShootProblem
+    case = CASES[name]
+    eq, mode, m, _ = case
+    gi = ShootProblem(eq, mode, m, ctx=ieee_ctx)
+    gd = ShootProblem(eq, mode, m, ctx=es_ctx)
+    port = cases.port_problem(eq, mode, m)
+    k, W = cases.sample_kw(case, nk=6, nw=160, seed=17)
+    Di, sti, reli = (t.cpu().numpy() for t in gi.eval_grid(k, W, want_rel=True))
+    Dd, std = (t.cpu().numpy() for t in gd.eval_grid(k, W))
+    Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=8)
+    assert np.array_equal(sti, stp) and np.array_equal(std, stp)
+    ev = (stp == 0) | (stp == 3)                      # evaluated points (continuum points are marched too)
+    assert ev.sum() > 100
+    same = Di[ev] == Dp[ev]
+    scale = np.abs(Dp[ev]) * 100.0 / relp[ev]
+    if name.startswith("SD_"):
+        assert np.all(same), (name, int((~same).sum()), int(ev.sum()))
+        assert np.array_equal(reli[ev], relp[ev])
+    else:
+        err = np.abs(Di[ev] - Dp[ev]) / scale
+        print(f"{name}: {int(same.sum())} of {int(ev.sum())} points bitwise equal, max |dD|/scale {err.max():.2e}")
+        assert same.mean() > 0.5 and err.max() < 2e-14, (name, same.mean(), err.max())
+        assert np.array_equal(np.signbit(Di[ev]), np.signbit(Dp[ev])) or np.all(
+            np.abs(Dp[ev][np.signbit(Di[ev]) != np.signbit(Dp[ev])]) < 2e-14 * scale[np.signbit(Di[ev]) != np.signbit(Dp[ev])])
+    ok = stp == 0
+    sc = np.abs(Dp[ok]) * 100.0 / relp[ok]
+    assert np.max(np.abs(Dd[ok] - Di[ok]) / sc) < D_RTOL
+    gi.close()
+    gd.close()
 
 
 @pytest.mark.parametrize("name", ["CF_flow_kink", "CR_kink", "SD_w15_kink", "SFG_flow_sausage"])

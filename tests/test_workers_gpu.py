@@ -24,22 +24,8 @@ class Sink:
 
 
 def _solvers(es_ctx):
-    import eigensolver_amd as E
-    return {
-        "CF_uniform": (E.CylinderNonUniformFlow(ctx=es_ctx), "CF"),
-        "CF_flow": (E.CylinderNonUniformFlow(U_i0=0.6, width=1.0, ctx=es_ctx), "CF"),
-        "CDC_w095": (E.CylinderNonUniformDensity(width=0.95, ctx=es_ctx), "CD-C"),
-        "CDC_uniform": (E.CylinderNonUniformDensity(width=1e5, ctx=es_ctx), "CD-C"),
-        "CDP": (E.CylinderNonUniformDensity(width=0.9, photospheric=True, ctx=es_ctx), "CD-P"),
-        "CRKF": (E.CylinderRotationalFlow(v_twist=0.25, power=0.8, variant="kink_fast", ctx=es_ctx), "CR-KF"),
-        "CRKS": (E.CylinderRotationalFlow(v_twist=0.1, power=0.8, variant="kink_slow", ctx=es_ctx), "CR-KS"),
-        "CRSF": (E.CylinderRotationalFlow(v_twist=0.15, power=1.25, variant="sausage", ctx=es_ctx), "CR-SF"),
-        "SFU": (E.SlabUniformFlow(ctx=es_ctx), "SF-U"),
-        "SFG_uniform": (E.SlabNonUniformFlow(U_i0=0.9, width=1e5, ctx=es_ctx), "SF-G"),
-        "SFG_flow": (E.SlabNonUniformFlow(U_i0=0.35, width=1.5, ctx=es_ctx), "SF-G"),
-        "SDP_uniform": (E.SlabNonUniformDensity(width=1e5, ctx=es_ctx), "SD-P"),
-        "SDP_w15": (E.SlabNonUniformDensity(width=1.5, ctx=es_ctx), "SD-P"),
-    }
+    from tests import refcases
+    return {name: (factory(es_ctx), key) for name, (key, factory) in refcases.solver_factories().items()}
 
 
 def _port_evaluator(solver, mode):
@@ -63,12 +49,22 @@ def _port_evaluator(solver, mode):
     return evaluate
 
 
-@pytest.mark.parametrize("name", ["CF_uniform", "CF_flow", "CDC_w095", "CDP", "CRKF", "CRKS", "CRSF", "SFU",
-                                  "SFG_flow", "SDP_w15"])
+def _trace_names():
+    from tests import refcases
+    return refcases.trace_names()
+
+
+def _rootset_names():
+    from tests import refcases
+    return refcases.rootset_names()
+
+
+@pytest.mark.parametrize("name", _trace_names())
 def test_worker_vs_oracle_state_machine(es_ctx, name):
+    """Every traced call: the GPU worker equals the oracle state machine driven by the CPU port -- same roots bit for
+    bit, same number of evaluations the reference worker would perform."""
     solver, key = _solvers(es_ctx)[name]
     tr = json.load(open(os.path.join(G, f"trace_{name}.json")))
-    n_roots = 0
     for call in tr["calls"]:
         mode = call["fn"]
         spec = OW.SPECS[(key, mode)]
@@ -78,31 +74,34 @@ def test_worker_vs_oracle_state_machine(es_ctx, name):
         assert int(nev[0]) == len(requested), (name, mode, call["k"], int(nev[0]), len(requested))
         # roots are grid / linspace points: identical decisions give bit-identical values
         assert got[0] == ref_roots, (name, mode, call["k"])
-        n_roots += len(ref_roots)
     solver.close()
 
 
-@pytest.mark.parametrize("name", ["CF_uniform", "CF_flow", "CDC_w095", "CDC_uniform", "CDP", "CRKS", "CRSF",
-                                  "SFG_uniform", "SFG_flow", "SDP_uniform", "SDP_w15", "SFU"])
+AGREEMENT = json.load(open(os.path.join(G, "agreement_table.json")))
+
+
+@pytest.mark.parametrize("name", _trace_names())
 def test_worker_signature_vs_reference_roots(es_ctx, name):
-    """Same call as the reference made (k, freq): sausage/kink(wavenumber, ws_sink, ks_sink, freq).
-    Where the reference's acceptance decisions are not within its own LSODA noise of the tolerance, the reported
-    roots are the same linspace points -> |d omega / omega| < 1e-10 (north star)."""
+    """Same call as the reference made: sausage/kink(wavenumber, ws_sink, ks_sink, freq), one `put` per sink (k list
+    first).  Per call (no fraction): where tests/test_reference_agreement.py classifies the call "identical", the GPU
+    returns the reference's root list value for value, |d omega / omega| <= 1e-10 (north star); every other call is in
+    a committed, explained category (fsolve ier != 1 / singular point / measured LSODA exterior error / LSODA interior
+    tolerance) and the GPU returns exactly what the explained algorithm returns (previous test)."""
     solver, key = _solvers(es_ctx)[name]
     tr = json.load(open(os.path.join(G, f"trace_{name}.json")))
-    n_calls = n_same = n_roots = 0
-    for call in tr["calls"]:
+    cats = AGREEMENT[f"trace:{name}"]
+    assert len(cats) == len(tr["calls"])
+    for call, cat in zip(tr["calls"], cats):
         ws, ks = Sink(), Sink()
         getattr(solver, call["fn"])(call["k"], ws, ks, np.array(call["freq"]))
         assert len(ws.items) == 1 and len(ks.items) == 1 and len(ws.items[0]) == len(ks.items[0])
         assert all(k == call["k"] for k in ks.items[0])
         mine, ref = ws.items[0], call["roots_w"]
-        n_calls += 1
-        if len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref)):
-            n_same += 1
-            n_roots += len(ref)
-    # the reference is noisy at the 1e-4 level (fsolve/LSODA): decisions next to the tolerance may flip; most calls agree
-    assert n_same >= max(1, int(0.6 * n_calls)), (name, n_same, n_calls)
+        if cat == "identical":
+            assert len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref)), \
+                (name, call["fn"], call["k"], mine, ref)
+        else:
+            assert cat in ("fsolve", "singular", "exterior", "interior_noise"), (name, cat)
     solver.close()
 
 
@@ -144,52 +143,54 @@ def test_driver_block_layout(es_ctx):
     s.close()
 
 
-ROOTSET_SOLVERS = {
-    "CF_flow": ("CF_flow", "CF"), "CF_uniform": ("CF_uniform", "CF"), "CDC_w095": ("CDC_w095", "CD-C"),
-    "SFG_flow": ("SFG_flow", "SF-G"), "CRKS": ("CRKS", "CR-KS"), "CRSF": ("CRSF", "CR-SF"),
-    "SDP_w15": ("SDP_w15", "SD-P"), "CDP": ("CDP", "CD-P"), "SFG_uniform": ("SFG_uniform", "SF-G"),
-}
-# sweeps that are only reported (tools/report_reference_agreement.py): in the checked-in CR-KF the reference's fsolve
-# fails (ier = 5) in most evaluations, so 4 of its 6 calls are artefacts; its 3 roots are all reproduced
-ROOTSET_REPORT_ONLY = {"CRKF": ("CRKF", "CR-KF")}
-
-
-@pytest.mark.parametrize("name", list(ROOTSET_SOLVERS))
+@pytest.mark.parametrize("name", _rootset_names())
 def test_driver_sweep_vs_reference_root_sets(es_ctx, name):
-    """Driver-style sweeps (k x band x mode, 30-40 point bands) of the reference workers executed in the build
-    container (tests/golden/roots_*.json): all calls of a sweep go to the GPU as ONE batch; the root lists must be
-    the reference's, value for value (|d omega/omega| < 1e-10), in every call where the reference's fsolve converged
-    throughout; the reference's remaining calls contain evaluations with a silently non-converged fsolve slope."""
-    path = os.path.join(G, f"roots_{name}.json")
-    if not os.path.exists(path):
-        pytest.skip("root set not generated")
-    solver, key = _solvers(es_ctx)[ROOTSET_SOLVERS[name][0]]
-    rs = json.load(open(path))
-    by_mode = {}
-    for c in rs["calls"]:
-        by_mode.setdefault((c["fn"], c["n"]), []).append(c)
-    n_clean = same_clean = n_dirty = same_dirty = 0
-    for (mode, n), calls in by_mode.items():
-        ks = [c["k"] for c in calls]
-        fr = np.stack([np.linspace(c["band"][0] * c["k"], c["band"][1] * c["k"], n) for c in calls])
-        got = solver.run_batch(mode, ks, fr)
-        for c, mine in zip(calls, got):
-            ref = c["roots_w"]
-            same = len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref))
-            if c["n_fsolve_fail"] == 0:
-                n_clean += 1
-                same_clean += same
-            else:
-                n_dirty += 1
-                same_dirty += same
-    assert n_clean + n_dirty >= 10
-    # every call in which the reference's fsolve converged at every evaluation is reproduced root for root
-    # (one knife-edge exception allowed per sweep: acceptance measure within LSODA noise of the tolerance)
-    assert same_clean >= n_clean - 1, (name, same_clean, n_clean)
-    # calls in which the reference silently used a non-converged fsolve slope (ier != 1, SURVEY section 5) are the
-    # reference's own artefacts; most still agree
-    assert n_dirty == 0 or same_dirty >= 0.5 * n_dirty, (name, same_dirty, n_dirty)
+    """Driver-style sweeps (k x band x mode) of the reference workers executed in the build container
+    (tests/golden/roots_*.json): all calls of a sweep go to the GPU as ONE batch per (mode, band length).  Per call:
+      * the GPU root list equals, bit for bit, what the oracle state machine + CPU port give (the algorithm whose
+        every difference from the reference is explained call by call in tests/test_reference_agreement.py);
+      * calls classified "identical" there reproduce the reference's root list, |d omega / omega| <= 1e-10."""
+    from tests import refcases
+    solver, key = _solvers(es_ctx)[name]
+    calls = refcases.load_calls("roots", name)
+    cats = AGREEMENT[f"roots:{name}"]
+    assert len(cats) == len(calls) >= 6
+    by_shape = {}
+    for i, c in enumerate(calls):
+        by_shape.setdefault((c["fn"], len(c["freq"])), []).append(i)
+    n_identical = 0
+    for (mode, n), idx in by_shape.items():
+        spec = OW.SPECS[(key, mode)]
+        got = solver.run_batch(mode, [calls[i]["k"] for i in idx], np.stack([calls[i]["freq"] for i in idx]))
+        ev = _port_evaluator(solver, mode)
+        for i, mine in zip(idx, got):
+            c = calls[i]
+            expect, _, _ = OW.run_worker(spec, ev, c["k"], c["freq"])
+            assert mine == expect, (name, mode, c["k"])
+            if cats[i] == "identical":
+                ref = c["roots_w"]
+                assert len(mine) == len(ref) and all(abs(a - b) <= 1e-10 * abs(b) for a, b in zip(mine, ref)), \
+                    (name, mode, c["k"], mine, ref)
+                n_identical += 1
+    assert n_identical == cats.count("identical")
     solver.close()
+
+
+def test_worker_eval_cap_is_reported(es_ctx, monkeypatch):
+    """A task that exceeds its evaluation bound is not silently truncated: es_worker_run returns ES_ERR_EVAL_CAP (the
+    Python layer raises) -- triggered here by lowering the bound (ES_WORKER_EVAL_CAP, a test aid) below what a deep
+    SF-U refinement chain (p_tol = 1e-6) needs."""
+    import eigensolver_amd as E
+    s = E.SlabUniformFlow(ctx=es_ctx)
+    f = np.linspace(0.3, 0.6, 12)[None, :]
+    full, nev = s.run_batch("sausage", [1.0], f, return_evals=True)
+    assert len(full[0]) >= 1 and int(nev[0]) > 40
+    monkeypatch.setenv("ES_WORKER_EVAL_CAP", "20")
+    with pytest.raises(E.EsError, match="evaluation cap"):
+        s.run_batch("sausage", [1.0], f)
+    monkeypatch.delenv("ES_WORKER_EVAL_CAP")
+    assert s.run_batch("sausage", [1.0], f) == full
+    s.close()
 
 
 @pytest.mark.parametrize("log_lanes", [0, 1, 3, 6])

@@ -63,6 +63,8 @@ def band(lo, hi, n):
     return ("band", lo, hi, n)
 
 
+SDC_IX = ("1e6)  # inside slab x values     #was 500", "2001)  # inside slab x values")
+
 CASES = {
     # cylinder, non-uniform flow file as checked in: uniform (dr = 1e5, U_i0 = 0)
     "CF_uniform": ("CF", [], [("kink", 1.5, band(2.05, 4.95, 14)), ("sausage", 1.5, band(2.05, 4.95, 14)),
@@ -95,6 +97,19 @@ CASES = {
     "SDP_w15": ("SD-P", [("1e5)  # inside slab x values", "2001)  # inside slab x values"), ("dx=1e5", "dx=1.5")],
                 [("sausage", 1.0, band(0.9, 1.25, 8)), ("kink", 1.0, band(0.9, 1.25, 8)),
                  ("kink", 2.5, band(0.9, 1.25, 8))]),
+    # coronal density slab as checked in (dx = 0.9, SD-C:110; p_tol = 1, SD-C:378), interior grid 2001 nodes instead of
+    # the checked-in 1e6 (SD-C:106); bands between the script's sorted `speeds` (SD-C:202), end points included as in
+    # its driver (SD-C:895)
+    "SDC_w09": ("SD-C", [SDC_IX], [("sausage", 1.0, band(0.9, 1.0, 8)), ("kink", 1.0, band(0.9, 1.0, 8)),
+                                   ("kink", 0.5, band(1.2, 1.3, 8)), ("sausage", 2.0, band(1.0923, 1.2, 8))]),
+    # SD-C in the uniform limit (dx = 1e5, the author's benchmark case; stored output width1e5_coronal.pickle): body
+    # modes between cT_i0 = 0.768 and c_i0 = 1 -- outside every continuum, unlike the checked-in dx = 0.9 bands
+    "SDC_uniform": ("SD-C", [SDC_IX, ("dx=0.9", "dx=1e5")], [("sausage", 1.0, band(0.78, 0.99, 8)),
+                                                             ("kink", 1.0, band(0.78, 0.99, 8)),
+                                                             ("kink", 2.5, band(0.78, 0.99, 8))]),
+    # slow sausage modes of the rotating cylinder as checked in (xi_tol = 4.5, CR-SS:423; speeds CR-SS:232)
+    "CRSS": ("CR-SS", [], [("sausage", 1.5, band(0.9, 0.92, 10)), ("sausage", 3.0, band(0.96, 0.98, 8)),
+                            ("sausage", 0.8, band(0.98, 1.0, 8))]),
 }
 
 
@@ -204,28 +219,77 @@ ROOTSETS = {
     "CDP": ("CD-P", [], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5], [(0.52, 1.48)], 30, ("kink", "sausage")),
     "SFG_uniform": ("SF-G", [], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.05, 2.45)], 30, ("kink", "sausage")),
     "CRKF": ("CR-KF", [], [0.6, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.21, 1.44)], 30, ("kink",)),
+    # the scripts the round-1 fixtures left out: SD-C (bands = consecutive sorted speeds of SD-C:202), CR-SS (CR-SS:232),
+    # and SF-U's own driver grid (SF-U:813: logspace(0.001, 0.55, 80) - 1 for every k, :838: the body band)
+    "SDC_w09": ("SD-C", [SDC_IX], [0.4, 0.9, 1.4, 2.0, 2.6, 3.2], [(0.9, 1.0), (1.2, 1.3)], 25, ("kink", "sausage")),
+    "SDC_uniform": ("SD-C", [SDC_IX, ("dx=0.9", "dx=1e5")], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0], [(0.78, 0.9), (0.9, 1.0)], 25,
+                    ("kink", "sausage")),
+    "CRSS": ("CR-SS", [], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5], [(0.9, 0.92), (0.94, 0.96), (0.98, 1.0)], 40, ("sausage",)),
+    "SFU": ("SF-U", [], [0.3, 0.9, 1.5, 2.1, 2.7, 3.3], ["sfu_log", "sfu_body"], 0, ("kink", "sausage")),
 }
 
 
+def rootset_freq(ns, spec, k, n):
+    """Frequencies of one driver task: (lo, hi) = band between two characteristic speeds (linspace(lo k, hi k, n), e.g.
+    CD-C:1145), "sfu_log" / "sfu_body" = the two task kinds of SF-U:813, :838."""
+    if spec == "sfu_log":
+        return np.logspace(0.001, 0.55, 80) - 1
+    if spec == "sfu_body":
+        return np.linspace(ns["cT_i"]() * k, (ns["c_e"] + ns["U_e"]) * k, 100)
+    return np.linspace(spec[0] * k, spec[1] * k, n)
+
+
 def gen_rootset(name):
+    """roots_<name>.json: per call the reference's root list and counters; roots_<name>_evals.npz: every determinant
+    evaluation of every call (call index, omega, mismatch d, exterior end state (value, slope), fsolve ier,
+    0 = main loop / 1 = inside locate_*) -- what tests/test_reference_agreement.py needs to explain every call whose
+    root list differs."""
     import ref_harness as H
     key, repl, ks, bands, n, modes = ROOTSETS[name]
     t0 = time.time()
     ns = H.load_worker_module(key, repl)
     init = H.snapshot_initial(ns)
     out = {"case": name, "file": H.FILES[key], "replacements": repl, "calls": []}
+    cols = {c: [] for c in ("call", "omega", "d", "ext_value", "ext_slope", "ier", "where")}
     for k in ks:
-        for lo, hi in bands:
-            freq = np.linspace(lo * k, hi * k, n)
+        for b in bands:
+            freq = rootset_freq(ns, b, float(k), n)
             for fn in modes:
                 rw, rk, tr = H.run_worker(ns, init, fn, float(k), freq)
                 iers = [e[3] for e in tr if e[0] == "fsolve"]
-                out["calls"].append({"fn": fn, "k": float(k), "band": [lo, hi], "n": n, "roots_w": rw,
-                                     "n_evals": len(H.evaluations(tr)), "n_fsolve_fail": int(sum(1 for i in iers if i != 1))})
+                evs = H.evaluations(tr)
+                rec = {"fn": fn, "k": float(k), "n": len(freq), "roots_w": rw, "n_evals": len(evs),
+                       "n_fsolve_fail": int(sum(1 for i in iers if i != 1))}
+                if isinstance(b, str):
+                    rec["freq_kind"] = b
+                    rec["freq"] = [float(x) for x in freq]
+                else:
+                    rec["band"] = [b[0], b[1]]
+                ci = len(out["calls"])
+                for e in evs:
+                    ext = e["ext_end"]
+                    if len(ext) == 4:               # odeintz: (re, im) pairs, im = 0
+                        ext = [ext[0], ext[2]]
+                    cols["call"].append(ci)
+                    cols["omega"].append(np.nan if e["omega"] is None else e["omega"])
+                    cols["d"].append(np.nan if e["d"] is None else e["d"])
+                    cols["ext_value"].append(ext[0])
+                    cols["ext_slope"].append(ext[1])
+                    cols["ier"].append(-1 if e["ier"] is None else e["ier"])
+                    cols["where"].append(1 if e["where"] == "loop" else (0 if e["where"] == "main" else -1))
+                out["calls"].append(rec)
     out["seconds"] = round(time.time() - t0, 1)
+    for k_ in ("xi_tol", "p_tol", "P_tol"):
+        if k_ in ns:
+            out[k_] = float(ns[k_])
     with open(os.path.join(GOLD, f"roots_{name}.json"), "w") as f:
         json.dump(out, f, indent=0)
-    return f"roots_{name}.json ({out['seconds']} s, {sum(len(c['roots_w']) for c in out['calls'])} roots)"
+    np.savez_compressed(os.path.join(GOLD, f"roots_{name}_evals.npz"),
+                        call=np.array(cols["call"], dtype=np.int32), omega=np.array(cols["omega"]),
+                        d=np.array(cols["d"]), ext_value=np.array(cols["ext_value"]),
+                        ext_slope=np.array(cols["ext_slope"]), ier=np.array(cols["ier"], dtype=np.int8),
+                        where=np.array(cols["where"], dtype=np.int8))
+    return f"roots_{name}.json ({out['seconds']} s, {sum(len(c['roots_w']) for c in out['calls'])} roots, {len(cols['call'])} evals)"
 
 
 if __name__ == "__main__":
