@@ -80,10 +80,31 @@ def measured_traffic_per_launch():
 
 
 def host_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands each
+    job a share of the host, e.g. 16 of 256 hardware threads)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]              # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())        # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    env = os.environ.get("ES_BENCH_CPU_CORES")
+    if env:
+        n = max(1, int(env))
+    return n
 
 
 def cpu_baselines(eq, m, k_np, W_np, target_seconds=10.0):

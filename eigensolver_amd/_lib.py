@@ -155,6 +155,7 @@ def _sig(lib):
     lib.es_problem_create.argtypes = [vp, C.POINTER(ShootDesc), C.POINTER(Profiles), C.POINTER(vp)]
     lib.es_problem_destroy.argtypes = [vp, vp]
     lib.es_shoot_eval_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, vp]
+    lib.es_shoot_eval_grid_ex.argtypes = [vp, vp, vp, i, vp, i, i, i, vp, vp, vp]
     lib.es_shoot_eval_points.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
     lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
     lib.es_worker_run.argtypes = [vp, vp, C.POINTER(WorkerSpec), vp, i, vp, i, vp, vp, i, vp]

@@ -19,6 +19,10 @@ struct es_context {
   // general call scratch (worker tables and frame stacks, refinement start data): grown on demand, never shrunk;
   // calls on one context are serialised by its stream, so one buffer suffices
   void* d_scratch = nullptr;       size_t scratch_cap = 0;
+  // live-column list of es_shoot_eval_grid_ex(ES_EVAL_SKIP_CONTINUUM): [0] = count, [1..] = column indices; per-column
+  // dead flags behind it
+  int* d_cols = nullptr;           size_t cols_cap = 0;
+  uint8_t* d_coldead = nullptr;
 };
 
 #define ES_HIP_CHECK(ctx, expr)                                                                 \

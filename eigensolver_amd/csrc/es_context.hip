@@ -51,6 +51,8 @@ extern "C" int es_context_destroy(es_context* ctx) {
   if (ctx->d_masks) (void)hipFree(ctx->d_masks);
   if (ctx->d_block_counts) (void)hipFree(ctx->d_block_counts);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_cols) (void)hipFree(ctx->d_cols);
+  if (ctx->d_coldead) (void)hipFree(ctx->d_coldead);
   if (ctx->d_total) (void)hipFree(ctx->d_total);
   if (ctx->h_total) (void)hipHostFree(ctx->h_total);
   delete ctx;

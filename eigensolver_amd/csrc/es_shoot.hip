@@ -23,12 +23,19 @@ namespace {
 using namespace es_shoot_shared;
 
 // ------------------------------------------------------------------------------------------------------------
+// Options of one grid launch: skip = ES_EVAL_SKIP_CONTINUUM; cols != nullptr: only the omega-columns cols[1 .. cols[0]]
+// are evaluated (live-column list built on the device by column_classify_kernel), the others were filled beforehand.
+struct GridOpts {
+  int skip;
+  const int* cols;
+};
+
 template <int FAM, int PTS, int MAXT, bool TRACK, int WPE = 0>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
 void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
                                                           const double* __restrict__ wv, int nw, int w_mode,
                                                           double* __restrict__ Dout, double* __restrict__ relout,
-                                                          uint8_t* __restrict__ stout) {
+                                                          uint8_t* __restrict__ stout, GridOpts opts) {
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr int LSTRIDE = 2 * CH + 1;
   // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
@@ -47,21 +54,25 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
   // launch is one segment long instead of one row)
   const int nseg = (nw + T * PTS - 1) / (T * PTS);
   const long ntiles = (long)nk * nseg;
+  const int ncols = opts.cols ? opts.cols[0] : nw;     // columns to evaluate (workgroup-uniform)
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row = (int)(tile / nseg);
+    const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
+    if (w0 >= ncols) continue;                         // segment beyond the live columns
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
     {
-      const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
       double w[PTS], zp[PTS], zq[PTS];
       Coef B0[PTS], B1[PTS];
       SignTrack trk[PTS];
       bool inr[PTS];
+      int iwp[PTS];
 #pragma unroll
       for (int p = 0; p < PTS; ++p) {
-        const int iw = w0 + p * T + (int)threadIdx.x;
-        inr[p] = iw < nw;
-        w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
+        const int ic = w0 + p * T + (int)threadIdx.x;
+        inr[p] = ic < ncols;
+        iwp[p] = inr[p] ? (opts.cols ? opts.cols[1 + ic] : ic) : 0;
+        w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iwp[p]) : 1.0;
       }
       // exterior closed form first: here only w[] is live, so the ~100 VGPRs of the Bessel code overlap with nothing
       // and only its three results per point are carried through the march (no call frame, no scratch)
@@ -72,7 +83,9 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
 #pragma unroll
       for (int p = 0; p < PTS; ++p) {
         X[p] = exterior_lite(P, k, w[p], w[p]);
-        lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK);
+        // with ES_EVAL_SKIP_CONTINUUM a point inside a continuum band (known before the march) is not worth a march
+        const bool dead = opts.skip && !TRACK && band_crossed(P, k, w[p]);
+        lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK && !dead);
         if (STASH) {                                   // parked at once: not live during the next Bessel evaluation
           double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;
           xs[0] = X[p].outer; xs[MAXT] = X[p].yb; xs[2 * MAXT] = X[p].Oe; xs[3 * MAXT] = (double)X[p].status;
@@ -159,16 +172,92 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
 #pragma unroll
       for (int p = 0; p < PTS; ++p) {
         if (!inr[p]) continue;
-        const int iw = w0 + p * T + (int)threadIdx.x;
+        const int iw = iwp[p];
         const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X[p], zp[p], zq[p], ef);
         double D, rel; uint8_t st;
         finish_point(P, M, X[p], TRACK ? trk[p].crossed() : band_crossed(P, k, w[p]), D, rel, st);
+        if (opts.skip && st == ES_PT_CONTINUUM) { D = NAN; rel = NAN; }
         const size_t o = (size_t)row * nw + iw;
         Dout[o] = D;
         stout[o] = st;
         if (relout) relout[o] = rel;
       }
     }
+  }
+}
+
+// ---- ES_EVAL_SKIP_CONTINUUM with ES_W_PHASE_SPEED: whole omega-columns inside a continuum band ----------------------
+// band_crossed() tests W' = (k W)/k, which is W up to the two roundings of the product and the quotient (|W' - W| <= 2
+// ulp).  A column is removed from the launch only if W is inside a band by more than that for every k:
+//     W - m > min lo  and  W + m < max hi  and  (W + m <= max lo  or  W - m >= min hi),      m = 4 ulp(W);
+// columns within the margin of a band edge stay in the launch and are flagged point by point as before.
+__device__ __forceinline__ bool column_dead(const ShootDev& P, double W) {
+  const double m = 4.0 * 2.220446049250313e-16 * fabs(W);
+  bool c = false;
+  for (int t = 0; t < P.n_bands; ++t) {
+    const bool some = (W - m > P.band[t][0]) && (W + m < P.band[t][3]);
+    const bool notall = (W + m <= P.band[t][1]) || (W - m >= P.band[t][2]);
+    c = c || (some && notall);
+  }
+  return c;
+}
+
+// One workgroup: dead flag per column + ordered list of the live columns (cols[0] = count, cols[1..] = indices).
+__global__ __launch_bounds__(1024) void column_classify_kernel(ShootDev P, const double* __restrict__ Wv, int nw,
+                                                               int* __restrict__ cols, uint8_t* __restrict__ dead) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < nw; j0 += 1024) {
+    const int j = j0 + tid;
+    const bool in = j < nw;
+    const bool dd = in && column_dead(P, Wv[j]);
+    if (in) dead[j] = dd ? 1 : 0;
+    const bool live = in && !dd;
+    const uint64_t m = __ballot(live);
+    if (lane == 0) wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int v = 0; v < wid; ++v) off += wave_cnt[v];
+    const uint64_t lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (live) cols[1 + off + __popcll(m & lower)] = j;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int v = 0; v < 16; ++v) t += wave_cnt[v]; base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) cols[0] = base;
+}
+
+// D = rel = NaN, status = CONTINUUM at every point of a dead column (status of a leaky / singular exterior takes
+// precedence, exactly as finish_point() orders them: the exterior is evaluated here, it is cheap next to a march).
+__global__ __launch_bounds__(256) void fill_dead_columns_kernel(ShootDev P, const double* __restrict__ kv, int nk,
+                                                                const double* __restrict__ wv, int nw,
+                                                                const uint8_t* __restrict__ dead,
+                                                                double* __restrict__ Dout, double* __restrict__ relout,
+                                                                uint8_t* __restrict__ stout) {
+  const long cells = (long)nk * nw;
+  for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (long)gridDim.x * blockDim.x) {
+    const long row = c / nw;
+    const int j = (int)(c - row * nw);
+    if (!dead[j]) continue;
+    const double k = kv[row];
+    const double w = k * wv[j];
+    // exterior status from m_e and the exterior constant alone (the Bessel evaluation is not needed for it)
+    const double k2 = k * k;
+    const double Oe = (P.family == FAM_CYL0 || P.family == FAM_CYLT) ? w : (w - k * P.U_e);
+    const double Oe2 = Oe * Oe;
+    const double m_e = ((k2 * P.vAe2 - Oe2) * (k2 * P.ce2 - Oe2)) / (P.Se * (k2 * P.cTe2 - Oe2));
+    const double cst = (P.family == FAM_CYL0 || P.family == FAM_CYLT)
+                           ? -1.0 / (P.rho_e * (k2 * P.vAe2 - w * w))
+                           : P.rho_e * P.Se * (k2 * P.cTe2 - Oe2) / (Oe * (k2 * P.ce2 - Oe2));
+    uint8_t st = ES_PT_CONTINUUM;
+    if (m_e < 0.0) st = ES_PT_LEAKY;
+    else if (!(m_e > 0.0) || !isfinite(m_e) || !isfinite(cst)) st = ES_PT_NONFINITE;
+    Dout[c] = NAN;
+    if (relout) relout[c] = NAN;
+    stout[c] = st;
   }
 }
 
@@ -319,7 +408,32 @@ int check_problem(es_context* ctx, const es_problem* prob) {
 // ES_GRID_VARIANT in the environment overrides the default (tuning aid).
 template <int FAM>
 int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
-                int w_mode, double* d_D, double* d_rel, uint8_t* d_status) {
+                int w_mode, double* d_D, double* d_rel, uint8_t* d_status, int flags = 0) {
+  GridOpts opts;
+  opts.skip = (flags & ES_EVAL_SKIP_CONTINUUM) ? 1 : 0;
+  opts.cols = nullptr;
+  if (opts.skip && w_mode == ES_W_PHASE_SPEED && fam_has_bands<FAM>() && prob->dev.use_bands) {
+    // live-column list on the device, dead columns filled at once; the grid launch below is sized for all nw
+    // columns (the count stays on the device), workgroups beyond the live ones return immediately
+    if ((size_t)nw + 1 > ctx->cols_cap) {
+      ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_cols) ES_HIP_CHECK(ctx, hipFree(ctx->d_cols));
+      if (ctx->d_coldead) ES_HIP_CHECK(ctx, hipFree(ctx->d_coldead));
+      ctx->d_cols = nullptr; ctx->d_coldead = nullptr; ctx->cols_cap = 0;
+      ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_cols, ((size_t)nw + 1) * sizeof(int)));
+      ES_HIP_CHECK(ctx, hipMalloc(&ctx->d_coldead, (size_t)nw));
+      ctx->cols_cap = (size_t)nw + 1;
+    }
+    hipLaunchKernelGGL(column_classify_kernel, dim3(1), dim3(1024), 0, ctx->stream, prob->dev, d_w, nw, ctx->d_cols,
+                       ctx->d_coldead);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    const long cells = (long)nk * nw;
+    const int fb = (int)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
+    hipLaunchKernelGGL(fill_dead_columns_kernel, dim3(fb), dim3(256), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw,
+                       ctx->d_coldead, d_D, d_rel, d_status);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    opts.cols = ctx->d_cols;
+  }
   int variant = (nw >= 2048) ? ((FAM == FAM_CYL0) ? 3 : 1) : ((nw >= 1024) ? 0 : 2);
   if (const char* ev = getenv("ES_GRID_VARIANT")) variant = atoi(ev);
   auto roundT = [](int pts_needed, int maxT) {
@@ -336,10 +450,10 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
     const int grid = (int)(tiles_ < (1L << 22) ? tiles_ : (1L << 22));                                              \
     if (bands)                                                                                                      \
       hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, !fam_has_bands<FAM>(), WPE>), dim3(grid), dim3(T), 0,   \
-                         ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                   \
+                         ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);             \
     else                                                                                                            \
       hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, true, WPE>), dim3(grid), dim3(T), 0, ctx->stream,       \
-                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status);                                \
+                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);                          \
   } while (0)
 #define ES_LAUNCH_GRID(PTS, MAXT, T) ES_LAUNCH_GRID_W(PTS, MAXT, T, 0)
   if (variant == 3 && FAM != FAM_CYL0) variant = 1;          // the register-capped shape exists for FAM_CYL0 only
@@ -560,20 +674,27 @@ extern "C" int es_problem_destroy(es_context* ctx, es_problem* prob) {
   return ES_SUCCESS;
 }
 
-extern "C" int es_shoot_eval_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
-                                  const double* d_w, int nw, int w_mode, double* d_D, double* d_rel,
-                                  uint8_t* d_status) {
+extern "C" int es_shoot_eval_grid_ex(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                     const double* d_w, int nw, int w_mode, int flags, double* d_D, double* d_rel,
+                                     uint8_t* d_status) {
   if (!ctx) return ES_ERR_INVALID_ARG;
   int rc = check_problem(ctx, prob);
   if (rc) return rc;
   ES_REQUIRE(ctx, nk >= 0 && nw >= 0, "negative size");
   ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  ES_REQUIRE(ctx, (flags & ~ES_EVAL_SKIP_CONTINUUM) == 0, "unknown flags");
   if (nk == 0 || nw == 0) return ES_SUCCESS;
   ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-#define CALL_GRID(F) launch_grid<F>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status)
+#define CALL_GRID(F) launch_grid<F>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, flags)
   ES_DISPATCH_FAMILY(prob->dev.family, CALL_GRID)
 #undef CALL_GRID
+}
+
+extern "C" int es_shoot_eval_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                  const double* d_w, int nw, int w_mode, double* d_D, double* d_rel,
+                                  uint8_t* d_status) {
+  return es_shoot_eval_grid_ex(ctx, prob, d_k, nk, d_w, nw, w_mode, 0, d_D, d_rel, d_status);
 }
 
 extern "C" int es_shoot_eval_points(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w,

@@ -86,8 +86,9 @@ class ShootProblem:
             return a.to(device=dev, dtype=torch.float64).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
 
-    def eval_grid(self, k, w, w_mode=W_PHASE_SPEED, want_rel=False):
-        """D[ik, iw], status[ik, iw] (and rel) on the (k, omega) grid; w_mode selects how omega is formed."""
+    def eval_grid(self, k, w, w_mode=W_PHASE_SPEED, want_rel=False, skip_continuum=False):
+        """D[ik, iw], status[ik, iw] (and rel) on the (k, omega) grid; w_mode selects how omega is formed.
+        skip_continuum: ES_EVAL_SKIP_CONTINUUM -- points inside a continuum band get D = NaN and are not marched."""
         import torch
         dk, dw = self._dev(k).reshape(-1), self._dev(w)
         nk = dk.numel()
@@ -97,8 +98,9 @@ class ShootProblem:
         D = torch.empty((nk, nw), dtype=torch.float64, device=dk.device)
         st = torch.empty((nk, nw), dtype=torch.uint8, device=dk.device)
         rel = torch.empty((nk, nw), dtype=torch.float64, device=dk.device) if want_rel else None
-        rc = self.ctx.lib.es_shoot_eval_grid(self.ctx.handle, self.handle, _lib.ptr(dk), nk, _lib.ptr(dw), nw,
-                                             w_mode, _lib.ptr(D), _lib.ptr(rel) if want_rel else None, _lib.ptr(st))
+        rc = self.ctx.lib.es_shoot_eval_grid_ex(self.ctx.handle, self.handle, _lib.ptr(dk), nk, _lib.ptr(dw), nw,
+                                                w_mode, 1 if skip_continuum else 0, _lib.ptr(D),
+                                                _lib.ptr(rel) if want_rel else None, _lib.ptr(st))
         _lib.check(self.ctx.handle, rc)
         return (D, st, rel) if want_rel else (D, st)
 

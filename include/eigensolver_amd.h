@@ -152,6 +152,20 @@ int es_shoot_eval_grid(es_context* ctx, const es_problem* prob, const double* d_
                        const double* d_w, int nw, int w_mode,
                        double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
 
+/* es_shoot_eval_grid with options.  flags = 0 is es_shoot_eval_grid.
+ * ES_EVAL_SKIP_CONTINUUM: points whose status is ES_PT_CONTINUUM get D = rel = NaN instead of the value a march
+ * through the singular layer gives (the reference integrates through it with LSODA and returns integrator noise,
+ * which the grid search never brackets -- es_shoot_find_roots requires both ends ES_PT_OK).  Where the flag can be
+ * decided before the march (families with connected continuum bands in phase speed) such points
+ * are not marched at all; with ES_W_PHASE_SPEED whole omega-columns inside a band are removed from the launch
+ * (ordered compaction of the live columns on the device, no host synchronisation).  D and rel are identical to
+ * flags = 0 at every point whose status is not ES_PT_CONTINUUM; statuses are identical except that a continuum point
+ * whose march would have overflowed (ES_PT_NONFINITE with flags = 0) is reported ES_PT_CONTINUUM. */
+enum { ES_EVAL_SKIP_CONTINUUM = 1 };
+int es_shoot_eval_grid_ex(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                          const double* d_w, int nw, int w_mode, int flags,
+                          double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
+
 /* The same determinant at n arbitrary (k, omega) pairs (one pair per lane, no shared k). */
 int es_shoot_eval_points(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w, int n,
                          double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);

@@ -362,3 +362,46 @@ def test_node_count_extremes_cylinder(es_ctx, n_nodes):
     Dq, sq = gp.eval_points(kk, ww)
     assert np.array_equal(Dq.cpu().numpy().reshape(3, 64), D[:, ::32], equal_nan=True)
     gp.close()
+
+
+@pytest.mark.parametrize("name,w_mode", [("CF_flow_kink", 1), ("CF_flow_sausage", 1), ("CDC_w095_kink", 1), ("CF_flow_m3", 1),
+                                         ("SD_w15_kink", 1), ("SFG_flow_kink", 1), ("CR_kink", 1), ("CF_flow_kink", 2)])
+def test_skip_continuum_flag(es_ctx, name, w_mode):
+    """es_shoot_eval_grid_ex(ES_EVAL_SKIP_CONTINUUM): statuses as without the flag; D and rel bit-identical at every
+    point that is not ES_PT_CONTINUUM, NaN at the continuum points; with ES_W_PHASE_SPEED whole columns inside a band
+    leave the launch (device-side column compaction) -- rows wider than one omega-segment, ragged sizes, a column
+    exactly on a band edge (kept in the launch by the margin test) and the per-row mode (no compaction) included."""
+    case = CASES[name]
+    eq, mode, m, (lo, hi) = case
+    gp = _gpu_problem(es_ctx, case)
+    k = np.linspace(0.3, 3.9, 5)
+    nw = 1500 if name == "CF_flow_kink" else 333
+    if name.startswith("CF_flow"):
+        lo = 0.9                          # include the cusp and Alfven bands of the flow profile
+    W = np.linspace(lo, hi, nw)
+    if name.startswith("CF_flow"):
+        # phase speeds exactly on the edges of the Alfven / cusp bands of this profile
+        vz = eq.v_z(np.array([-1.0, -1e-3]))
+        W[10], W[11] = vz[0] + eq.vA_i0, vz[1] + eq.vA_i0
+    if w_mode == 2:
+        wq = (k[:, None] * W[None, :]).copy()
+        D0, st0, rel0 = gp.eval_grid(k, wq, w_mode=2, want_rel=True)
+        D1, st1, rel1 = gp.eval_grid(k, wq, w_mode=2, want_rel=True, skip_continuum=True)
+    else:
+        D0, st0, rel0 = gp.eval_grid(k, W, want_rel=True)
+        D1, st1, rel1 = gp.eval_grid(k, W, want_rel=True, skip_continuum=True)
+    D0, st0, rel0, D1, st1, rel1 = (t.cpu().numpy() for t in (D0, st0, rel0, D1, st1, rel1))
+    cont = st0 == 3
+    assert np.array_equal(st0, st1), (name, np.argwhere(st0 != st1)[:5])
+    keep = ~cont
+    assert np.array_equal(D0[keep], D1[keep], equal_nan=True) and np.array_equal(rel0[keep], rel1[keep], equal_nan=True)
+    assert np.all(np.isnan(D1[cont])) and np.all(np.isnan(rel1[cont]))
+    if name.startswith(("CF_flow", "CDC", "SD_")):
+        assert cont.sum() > 20, (name, cont.sum())           # the window does contain continuum points
+    # brackets / roots are unaffected (both ends of a bracket must be ES_PT_OK)
+    if w_mode == 1:
+        import torch
+        r0, c0 = gp.find_roots(k, W, torch.as_tensor(D0, device="cuda"), torch.as_tensor(st0, device="cuda"), n_bisect=20)
+        r1, c1 = gp.find_roots(k, W, torch.as_tensor(D1, device="cuda"), torch.as_tensor(st1, device="cuda"), n_bisect=20)
+        assert c0 == c1 and np.array_equal(r0["w"].cpu().numpy(), r1["w"].cpu().numpy())
+    gp.close()
