@@ -37,9 +37,19 @@ sys.path.insert(0, ROOT)
 
 NK = NW = 4096
 W_LO, W_HI = 0.8944271909999159, 5.0          # (cT_i0, vA_e) of the coronal cylinder
-N_BISECT = 16                                 # bracket narrowed by >= 2^16 (6 rounds of 9-section: 9^6 = 5.3e5), then
-REFINE_ROUNDS = 6                             # two regula-falsi polish steps -> |d omega/omega| ~ 1e-16 (8 evals per round)
-REFINE_POLISH = 2
+N_BISECT = 16                                 # bracket narrowed by >= 2^16, then two regula-falsi polish steps
+REFINE_POLISH = 2                             # -> |d omega/omega| ~ 1e-16
+
+
+def refine_plan(n_brackets):
+    """(sections, rounds, distinct determinant evaluations per bracket) of es_shoot_find_roots for N_BISECT: 17-section
+    with 16 lanes per bracket up to 32768 brackets (4 rounds: 17^4 >= 2^16), 9-section with 8 lanes beyond (6 rounds)."""
+    sections = 17 if n_brackets <= 32768 else 9
+    rounds, span = 0, 1.0
+    while span < 2.0 ** N_BISECT:
+        span *= sections
+        rounds += 1
+    return sections, rounds, (sections - 1) * rounds + REFINE_POLISH
 TOL_PERCENT = 1e-3
 EXCHANGE_CAP = 1 << 15                        # records per rank in the fixed-capacity all-gather (6 doubles each)
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -49,7 +59,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 BYTES_PER_EVAL = 8.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 BYTES_PER_EVAL_WITH_STATUS = BYTES_PER_EVAL + 1.0
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-FLOPS_PER_STEP = 2 * 9 + 8 + 32             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step (32)
+FLOPS_PER_STEP = 2 * 9 + 8 + 28             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step in the scaled-coefficient form (8 fma, 2 fma-by-2, 6 add, 2 mul = 28)
 
 
 def workload_equilibrium():
@@ -169,11 +179,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("strong", "weak-m"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--march-continuum", action="store_true",
+                    help="march the points inside continuum bands too (round-1 behaviour); default: "
+                         "ES_EVAL_SKIP_CONTINUUM, they get D = NaN, are not marched and are NOT counted in `value`")
     ap.add_argument("--dump-roots", default=None, help="write the merged root table of the last step to this .npy")
+    ap.add_argument("--workload", choices=("config3", "config4"), default="config3",
+                    help="config3 (default, the headline): BASELINE.json configs[3]; config4: configs[4], Cylinder / "
+                         "rotational flow, m = 0..10, fp32 bracket + fp64 refine (a second, never the headline, line)")
+    ap.add_argument("--precision", choices=("mixed", "f64"), default="mixed", help="config4 only")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_children(a))
+    if a.workload == "config4":
+        return main_config4(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,7 +238,7 @@ def main():
     def step(ev=None):
         if ev is not None:
             ev[0].record()
-        D_, st = prob.eval_grid(k, W)
+        D_, st = prob.eval_grid(k, W, skip_continuum=not a.march_continuum)
         if ev is not None:
             ev[1].record()
         roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
@@ -246,7 +265,9 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     hist = torch.bincount(st.reshape(-1).to(torch.int64), minlength=4)[:4].to(torch.float64).to(cdev)
     n_acc = int((roots["flag"] == 1).sum())
-    counts = torch.tensor([float(nbr), float(n_acc), float(nk_local * NW)], dtype=torch.float64, device=cdev)
+    # grid points one step really evaluates: all of them, or (default) those outside the continuum bands
+    n_eval_local = nk_local * NW if a.march_continuum else int((st != 3).sum())
+    counts = torch.tensor([float(nbr), float(n_acc), float(n_eval_local)], dtype=torch.float64, device=cdev)
     grid_ms_t = torch.tensor([float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,9 +290,10 @@ def main():
     if rank == 0:
         if a.dump_roots and merged is not None:
             np.save(a.dump_roots, merged)
-        evals_per_step = grid_points + brackets_total * (8 * REFINE_ROUNDS + REFINE_POLISH)
+        sections, rounds, ev_per_bracket = refine_plan(brackets_total // world)
+        evals_per_step = grid_points + brackets_total * ev_per_bracket
         value = evals_per_step * a.steps / dt
-        launch_evals = nk_local * NW                     # points one launch of the dominant kernel processes (rank 0)
+        launch_evals = n_eval_local                      # points one launch of the dominant kernel evaluates (rank 0)
         achieved = launch_evals * BYTES_PER_EVAL / (grid_ms * 1e-3) / 1e9
         nsteps = eq.n_nodes - 1
         tflops = launch_evals * FLOPS_PER_STEP * nsteps / (grid_ms * 1e-3) / 1e12
@@ -295,13 +317,19 @@ def main():
                                    "Cylinder / non-uniform (Gaussian) axial flow, coronal, m = rank+1, 4096x4096 "
                                    "(k,omega) grid per GPU, fp64 (BASELINE.json configs[3], (k, m) tiling)",
                        "nk": NK, "nw": NW, "k_rows_per_gpu": nk_local, "interior_nodes": eq.n_nodes,
-                       "n_bisect": N_BISECT, "refine_rounds_9section": REFINE_ROUNDS, "refine_polish_steps": REFINE_POLISH,
+                       "n_bisect": N_BISECT, "refine_sections": sections, "refine_rounds": rounds,
+                       "refine_polish_steps": REFINE_POLISH, "refine_evals_per_bracket": ev_per_bracket,
                        "brackets_per_step": brackets_total, "roots_per_step": roots_total,
                        "gathered_root_records": int(merged.shape[0]) if (world > 1 and merged is not None) else 0,
                        "grid_point_status_fractions": frac,
-                       "status_note": "every grid point is marched and counted in `value`; continuum points (Omega^2 "
-                                      "crosses omega_A^2(r) or omega_c^2(r) inside the tube) are evaluated as the "
-                                      "reference does but never bracketed",
+                       "grid_points_evaluated_per_step": grid_points,
+                       "status_note": ("every grid point is marched and counted in `value`; continuum points (Omega^2 "
+                                       "crosses omega_A^2(r) or omega_c^2(r) inside the tube) are evaluated as the "
+                                       "reference does but never bracketed") if a.march_continuum else
+                                      ("ES_EVAL_SKIP_CONTINUUM: points inside a continuum band (Omega^2 crosses "
+                                       "omega_A^2(r) or omega_c^2(r) inside the tube; the reference returns integrator "
+                                       "noise there and the grid search never brackets them) get D = NaN, are NOT "
+                                       "marched and are NOT counted in `value`; --march-continuum restores round 1"),
                        "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": "shoot_grid_kernel<FAM_CYL0>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -317,6 +345,103 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_config4(a):
+    """BASELINE.json configs[4]: Cylinder / rotational flow (v_phi = 0.1 r, photospheric constants of
+    Twisted_photospheric_*.py), azimuthal orders m = 0..10, 1024 x 1024 (k, omega) grid per order, N = 2000 interior
+    nodes.  One step = all orders owned by the rank: fp32 screening march + fp64 re-evaluation of the unsure points
+    and of both ends of every bracket + fp64 refinement (es_shoot_find_roots_mixed), or with --precision f64 the fp64
+    path (es_shoot_eval_grid + es_shoot_find_roots) -- the two give bit-identical root tables
+    (tests/test_mixed_gpu.py).  N > 1: the orders are dealt round-robin to the ranks, one all-gather of the root
+    tables per step."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("ES_BENCH_BACKEND", "nccl")
+    if os.environ.get("ES_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
+    from eigensolver_amd import ShootProblem, _lib, equilibrium as q
+    from eigensolver_amd import distributed as D
+    dev = torch.device(f"cuda:{local_rank}")
+    ctx = _lib.Context(local_rank)
+    n = 1024
+    k = torch.linspace(0.25, 4.0, n, dtype=torch.float64, device=dev)
+    W = 0.7 + (torch.arange(n, dtype=torch.float64, device=dev) + 0.5) * ((1.45 - 0.7) / n)
+    orders = D.tile_modes(list(range(11)), rank, world)
+    probs = []
+    for m in orders:
+        eq = q.CylinderRotation(v_twist=0.1, power=1.0, r_axis=0.01 if m == 0 else 0.001)
+        probs.append((m, ShootProblem(eq, "sausage" if m == 0 else "kink", m=m, ctx=ctx)))
+    table = probs[0][1].alloc_root_table(1 << 17) if probs else None
+    rows_t = torch.arange(n, device=dev)
+    mixed = a.precision == "mixed"
+
+    def step():
+        tot_br = tot_acc = tot_re = 0
+        bufs = []
+        for m, prob in probs:
+            if mixed:
+                roots, nbr, _, _, stats = prob.find_roots_mixed(k, W, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
+                tot_re += stats[0] + stats[1]
+            else:
+                D_, st = prob.eval_grid(k, W)
+                roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
+            tot_br += nbr
+            tot_acc += int((roots["flag"] == 1).sum())
+            if world > 1:
+                bufs.append(D.pack_fixed(roots, nbr, m, rows_t, 1 << 13))
+        if world > 1:                                  # one all-gather per step (ranks own 1 or 2 orders: pad to 2)
+            while len(bufs) < 2:
+                bufs.append(torch.zeros_like(bufs[0]) if bufs else torch.zeros(((1 << 13) + 1, D.N_FIELDS), dtype=torch.float64, device=dev))
+            D.gather_fixed(torch.cat(bufs, dim=0), world)
+        return tot_br, tot_acc, tot_re
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        nbr, nacc, nre = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    counts = torch.tensor([float(nbr), float(nacc), float(nre), float(len(orders) * n * n)], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    nbr, nacc, nre, grid_points = (int(x) for x in counts.tolist())
+    if rank == 0:
+        evals = grid_points + nre + nbr * refine_plan(nbr // 11)[2]
+        out = {"metric": "det(M) evals/sec + roots/sec, Cylinder / rotational flow m = 0..10 (BASELINE.json configs[4])",
+               "value": evals * a.steps / dt, "unit": "det-evals/s", "roots_per_s": nacc * a.steps / dt,
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32 screening march + f64 re-evaluation / refinement" if mixed else "f64", "data": "synthetic",
+               "config": {"workload": "Cylinder / rotational flow (v_phi = 0.1 r), m = 0..10, 1024x1024 (k,omega) grid per "
+                                      "order, N = 2000 nodes (BASELINE.json configs[4]); NOT the headline",
+                          "precision": a.precision, "orders": 11, "grid_points_per_step": grid_points,
+                          "fp64_reevaluations_per_step": nre, "brackets_per_step": nbr, "roots_per_step": nacc,
+                          "parallelism": "single GPU" if world == 1 else f"orders m dealt round-robin to {world} ranks, one all-gather per step"}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,6 +25,7 @@ extern "C" const char* es_status_string(int s) {
     case ES_ERR_NO_DEVICE: return "no HIP device";
     case ES_ERR_UNSUPPORTED: return "unsupported configuration";
     case ES_ERR_EVAL_CAP: return "worker task exceeded its evaluation cap";
+    case ES_ERR_SCREENING: return "fp32-screened bracket not confirmed in fp64";
     default: return "unknown status";
   }
 }

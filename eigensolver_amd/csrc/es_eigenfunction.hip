@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void eigen_interior_kernel(ShootDev P, const do
   const ExteriorLite X = exterior_lite(P, k, w, w);
   // (1) adjoint march: the row of the transfer matrix picked by the far-end condition -> boundary state (u_b, v_b)
   load_base<FAM>(P, 2 * nsteps, b);
-  make_entry<FAM>(b, s, e);
+  make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
   Coef B0;
   coefficients<FAM>(e, P, s, w, B0, trk);
   double zp, zq;
@@ -54,11 +54,11 @@ __global__ __launch_bounds__(64) void eigen_interior_kernel(ShootDev P, const do
   for (int j = nsteps - 1; j >= 0; --j) {
     Coef Bm, B1;
     load_base<FAM>(P, 2 * j + 1, b);
-    make_entry<FAM>(b, s, e);
+    make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
     load_base<FAM>(P, 2 * j, b);
-    make_entry<FAM>(b, s, e2);
+    make_entry<FAM, fam_scaled<FAM>()>(b, s, e2);
     coefficients2<FAM>(e, e2, P, s, w, Bm, B1, trk);
-    rk4_step_adjoint<FamTraits<FAM>::SHAPE>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+    adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);      // same arithmetic as the determinant kernels
     B0 = B1;
   }
   // boundary state from the same algebra as the determinant

@@ -105,7 +105,7 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
         for (int i = threadIdx.x; i < 2 * nst + 1; i += T) {
           double b[FamTraits<FAM>::NB], e[NE];
           load_base<FAM>(P, 2 * c0 + i, b);
-          make_entry<FAM>(b, s, e);
+          make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
 #pragma unroll
           for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = e[f];
         }
@@ -133,7 +133,7 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
           _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                 \
             Coef Bm;                                                                        \
             coefficients2<FAM, TRACK>(em, e1, P, s, w[p], Bm, BOUT[p], trk[p]);             \
-            rk4_step_adjoint<FamTraits<FAM>::SHAPE>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);       \
+            adjoint_step<FAM>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);                             \
           }                                                                                 \
         }
         int j = nst - 1;
@@ -335,38 +335,44 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
   d_hi_sign[pos] = D[c + 1];
 }
 
-// Bracket refinement by 9-section: 8 lanes share one bracket (8 brackets per wave).  Per round the 8 lanes
-// evaluate D at the 8 interior points lo + (hi-lo)*(j+1)/9; a ballot collects "sign differs from D(lo)" and the
-// first set bit picks the sub-interval that keeps the sign change next to lo (the one a scan from lo would find,
-// as the reference's left-to-right 3-point refinement does).  n_rounds = ceil(n_bisect * ln2 / ln9) rounds shrink
-// the bracket at least as much as n_bisect bisections would; uniform trip count, no divergence.
-template <int FAM>
+// Bracket refinement by (LANES+1)-section: LANES lanes share one bracket (64/LANES brackets per wave).  Per round the
+// lanes evaluate D at the LANES interior points lo + (hi-lo)*(j+1)/(LANES+1); a ballot collects "sign differs from
+// D(lo)" and the first set bit picks the sub-interval that keeps the sign change next to lo (the one a scan from lo
+// would find, as the reference's left-to-right 3-point refinement does).  n_rounds = ceil(n_bisect ln2 / ln(LANES+1))
+// rounds shrink the bracket at least as much as n_bisect bisections would; uniform trip count, no divergence.
+// LANES = 16 (17-section: 4 rounds for n_bisect = 16 instead of the 6 of 9-section) while the launch stays below
+// a few waves per SIMD -- the kernel is bound by the sequential marches of one point per lane, not by throughput --
+// LANES = 8 for very many brackets (fewer evaluations in total); refine_sections() is the rule, mirrored by the port.
+__host__ __device__ inline int refine_sections(long n_brackets) { return n_brackets <= 32768 ? 17 : 9; }
+
+template <int FAM, int LANES>
 __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
                                                     const double* __restrict__ d_hi, int n, int n_rounds,
                                                     int n_polish, double tol_percent) {
   ES_POINT_LDS(FAM);
+  constexpr int GROUPS = 64 / LANES;
   const int lane = threadIdx.x & 63;
-  const int g = lane >> 3, j = lane & 7;
-  const int i = blockIdx.x * 8 + g;
+  const int g = lane / LANES, j = lane % LANES;
+  const int i = blockIdx.x * GROUPS + g;
   const bool in = i < n;
   const double k = in ? tab.d_k[i] : 1.0;
   double lo = in ? tab.d_w_lo[i] : 1.0;
   double hi = in ? tab.d_w_hi[i] : 2.0;
   double flo = in ? d_lo[i] : 1.0;
   double fhi = in ? d_hi[i] : -1.0;
-  const double frac = (double)(j + 1) / 9.0;
+  const double frac = (double)(j + 1) / (double)(LANES + 1);
   double D, rel; uint8_t st;
   for (int it = 0; it < n_rounds; ++it) {
     const double x = lo + (hi - lo) * frac;
     shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     const bool diff = (D * flo < 0.0);                 // NaN products compare false, as in the reference
-    const unsigned bits = (unsigned)((__ballot(diff) >> (8 * g)) & 0xFFull);
-    const int first = bits ? (__ffs((int)bits) - 1) : 8;         // first point whose sign differs from D(lo)
-    const int src_hi = (g << 3) + (first < 8 ? first : 7);
-    const int src_lo = (g << 3) + (first > 0 ? first - 1 : 0);
+    const unsigned bits = (unsigned)((__ballot(diff) >> (LANES * g)) & ((1ull << LANES) - 1ull));
+    const int first = bits ? (__ffs((int)bits) - 1) : LANES;     // first point whose sign differs from D(lo)
+    const int src_hi = g * LANES + (first < LANES ? first : LANES - 1);
+    const int src_lo = g * LANES + (first > 0 ? first - 1 : 0);
     const double x_hi = __shfl(x, src_hi), d_hi_new = __shfl(D, src_hi);
     const double x_lo = __shfl(x, src_lo), d_lo_new = __shfl(D, src_lo);
-    if (first < 8) { hi = x_hi; fhi = d_hi_new; }
+    if (first < LANES) { hi = x_hi; fhi = d_hi_new; }
     if (first > 0) { lo = x_lo; flo = (d_lo_new == d_lo_new) ? d_lo_new : flo; }
   }
   // Newton-type polish in fp64: regula-falsi (secant through the bracket ends) steps, every lane of the group the same
@@ -386,6 +392,332 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
     tab.d_resid[i] = rel;
     tab.d_flag[i] = (st == ES_PT_OK && rel < tol_percent) ? 1 : 0;
   }
+}
+
+// =====================================================================================================================
+// fp32 screening of the (k, omega) grid (BASELINE.json configs[4]: "fp32 bracket + fp64 refine").
+//
+// The bracket search only needs the SIGN of D at the grid points and the per-point status.  shoot_grid_f32_kernel
+// marches the interior in fp32 (node entries formed in fp64 per row and rounded once into the LDS table; exterior and
+// boundary algebra stay fp64) and marks every point at which fp32 cannot vouch for sign or status as UNSURE
+// (status bit 0x80):
+//   * a watched term of the coefficient set (Om^2 - omega_A^2, Om^2 - omega_c^2; C3 for the twisted family) comes
+//     within F32_TAU_NODE (1e-3) of zero relative to the size of its parts at some node (near-singular coefficient: large
+//     relative error in fp32, and the sign tracking that decides ES_PT_CONTINUUM is not reliable);
+//   * |D| < F32_TAU_D * max(|outer|, |inner|)  (a root is close: the sign is within the fp32 error of the march);
+//   * |outer| < F32_TAU_POLE * |inner|          (a pole of D is close: the sign of 1/r2 is within that error);
+//   * a non-finite fp32 result.
+// es_shoot_find_roots_mixed() re-evaluates the unsure points in fp64 (shoot_points_kernel, the arithmetic of the fp64
+// grid kernel bit for bit), detects the brackets on the merged array, re-evaluates BOTH ENDS of every bracket in fp64
+// (so the refinement starts from exactly the numbers the fp64 path has) and refines in fp64.
+constexpr float F32_TAU_NODE = 1e-3f;
+constexpr double F32_TAU_D = 5e-2;
+constexpr double F32_TAU_POLE = 5e-2;
+constexpr uint8_t F32_UNSURE = 0x80;
+
+struct CoefF { float a11, a12, a21, a22; };
+struct CoefPreF { float n11, n12, n21, n22, den; };
+
+// What the screening pass remembers per point about the watched terms (t1 = Om^2 - omega_A^2, t2 = Om^2 - omega_c^2 and,
+// twisted family, C3): running minimum and maximum of t1 and t2 over the nodes (2 instructions per term and node) and,
+// for C3, the sign bits of C3 D as in the fp64 kernel plus the minimum of |C3| - tau |D (rho t1 + r d/dr[..])| (how close C3
+// came to zero relative to its leading part).  With S = tau (omega^2 + omega_A^2(boundary)) a term is
+//   certainly of one sign   if min > S or max < -S,
+//   certainly crossing zero if min < -S and max > S   (=> ES_PT_CONTINUUM whatever happens next to the zero),
+//   anything else sends the point to fp64.
+struct ScreenF {
+  float lo1 = 3.0e38f, hi1 = -3.0e38f, lo2 = 3.0e38f, hi2 = -3.0e38f;
+  float c3m = 3.0e38f;
+  int or3 = 0, and3 = -1;
+};
+
+template <int FAM>
+__device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, float w, CoefPreF& C, ScreenF& sc) {
+  const float Om = w - e[0];
+  const float Om2 = Om * Om;
+  const float t1 = Om2 - e[1];
+  const float t2 = Om2 - e[2];
+  sc.lo1 = fminf(sc.lo1, t1); sc.hi1 = fmaxf(sc.hi1, t1);
+  sc.lo2 = fminf(sc.lo2, t2); sc.hi2 = fmaxf(sc.hi2, t2);
+  if (FAM == FAM_CYL0) {
+    C.n11 = 0.0f;
+    C.n12 = e[3] * t1;
+    C.n21 = fmaf(e[5], t2, e[6]);
+    C.n22 = e[4];
+    C.den = t1 * t2;
+  } else {
+    const float D = e[3] * t1 * t2;
+    const float Q = fmaf(Om, e[7], fmaf(Om2, e[6], -(t1 * e[5])));
+    const float T = fmaf(e[9], Om, e[8]);
+    const float OmP = (c1_power == 2) ? Om2 : Om;
+    const float t2T = t2 * T;
+    const float C1 = fmaf(Q, OmP, -(e[10] * t2T));
+    const float C2 = fmaf(Om2, Om2, -(e[11] * t2));
+    const float c3a = D * fmaf(e[4], t1, e[12]);
+    const float C3 = c3a + fmaf(Q, Q, -(e[13] * t2T * T));
+    const int b = __float_as_int(C3 * D);               // sign of F = r D / C3, third watched term of the fp64 kernel
+    sc.or3 |= b;
+    sc.and3 &= b;
+    sc.c3m = fminf(sc.c3m, fmaf(-F32_TAU_NODE, fabsf(c3a), fabsf(C3)));
+    C.n11 = -C1;
+    C.n22 = C1;
+    C.n12 = C3 * e[15];
+    C.n21 = -(e[14] * C2);
+    C.den = D;
+  }
+}
+
+template <int FAM>
+__device__ __forceinline__ void coef_finish_f32(const CoefPreF& C, float inv, CoefF& A) {
+  if (FAM == FAM_CYL0) {
+    A.a11 = 0.0f; A.a22 = 0.0f; A.a12 = C.n12; A.a21 = fmaf(C.n21, inv, C.n22);
+  } else {
+    A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
+  }
+}
+
+template <int FAM>
+__device__ __forceinline__ void rk4_step_adjoint_f32(float& p, float& q, const CoefF& B0, const CoefF& Bm, const CoefF& B1,
+                                                     float h, float h2, float h6, float h3) {
+#define ES_RHS_TF(A, pp, qq, kp, kq)                                                            \
+  if (FAM == FAM_CYLT) { kp = fmaf(A.a11, pp, A.a21 * qq); kq = fmaf(A.a22, qq, A.a12 * pp); } \
+  else                 { kp = A.a21 * qq;                  kq = A.a12 * pp; }
+  float k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
+  ES_RHS_TF(B0, p, q, k1p, k1q);
+  tp = fmaf(h2, k1p, p); tq = fmaf(h2, k1q, q);
+  ES_RHS_TF(Bm, tp, tq, k2p, k2q);
+  tp = fmaf(h2, k2p, p); tq = fmaf(h2, k2q, q);
+  ES_RHS_TF(Bm, tp, tq, k3p, k3q);
+  tp = fmaf(h, k3p, p); tq = fmaf(h, k3q, q);
+  ES_RHS_TF(B1, tp, tq, k4p, k4q);
+  p = fmaf(h6, k1p + k4p, fmaf(h3, k2p + k3p, p));
+  q = fmaf(h6, k1q + k4q, fmaf(h3, k2q + k3q, q));
+#undef ES_RHS_TF
+}
+
+// The adjoint march renormalised: fp32 has 8 bits of exponent, an evanescent interior grows like e^{kappa (1 - r_ax)}
+// (1e30 and more at large k).  Both components are scaled by a power of two whenever they leave [2^-40, 2^40]; the
+// boundary algebra only uses the ratio r1 : r2 and the (rescaled) target of the axis condition.
+// The closed-form exterior (fp64 Bessel code, ~100 VGPRs) is evaluated AFTER the march, when the loop state is dead;
+// before the march only the sign of m_e is needed to know which lanes have something to march.
+template <int FAM, int PTS, int MAXT, bool TRACK, int WPE>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, const double* __restrict__ wv, int nw,
+                           int w_mode, double* __restrict__ Dout, uint8_t* __restrict__ stout) {
+  constexpr int NE = FamTraits<FAM>::NE;
+  constexpr int LSTRIDE = 2 * CH + 1;
+  __shared__ float lds[NE * LSTRIDE];
+  const int T = blockDim.x;
+  const int nsteps = P.n_nodes - 1;
+  const float h = (float)P.h, h2 = (float)(0.5 * P.h), h6 = (float)(P.h / 6.0), h3 = (float)(P.h / 3.0);
+  const int nseg = (nw + T * PTS - 1) / (T * PTS);
+  const long ntiles = (long)nk * nseg;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row = (int)(tile / nseg);
+    const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
+    const double k = kv[row];
+    const KScal s = make_kscal(P, k);
+    float wf[PTS], zp[PTS], zq[PTS];
+    int zexp[PTS];                                     // accumulated power-of-two scaling of (zp, zq)
+    CoefF B0[PTS], B1[PTS];
+    ScreenF scr[PTS];
+    bool lane_live = false;
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+      const int iw = w0 + p * T + (int)threadIdx.x;
+      const double w = (iw < nw) ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
+      wf[p] = (float)w;
+      // m_e > 0 (evanescent exterior) and, for the band families, not inside a continuum band: worth a march
+      const double k2 = k * k, w2 = w * w;
+      const double m_e = ((k2 * P.vAe2 - w2) * (k2 * P.ce2 - w2)) / (P.Se * (k2 * P.cTe2 - w2));
+      const bool dead = !TRACK && band_crossed(P, k, w);
+      lane_live = lane_live || (iw < nw && m_e > 0.0 && !dead);
+      zp[p] = 0.0f; zq[p] = 0.0f; zexp[p] = 0;
+    }
+    const bool wave_live = __any(lane_live);
+    const bool wg_live = __syncthreads_or(wave_live ? 1 : 0) != 0;
+    const int nchunks = wg_live ? (nsteps + CH - 1) / CH : 0;
+    for (int c = nchunks - 1; c >= 0; --c) {
+      const int c0 = c * CH;
+      const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
+      __syncthreads();
+      for (int i = threadIdx.x; i < 2 * nst + 1; i += T) {
+        double b[FamTraits<FAM>::NB], e[NE];
+        load_base<FAM>(P, 2 * c0 + i, b);
+        make_entry<FAM>(b, s, e);                      // fp64, rounded to fp32 once
+#pragma unroll
+        for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = (float)e[f];
+      }
+      __syncthreads();
+      if (!wave_live) continue;
+      if (c == nchunks - 1) {
+        float eL[NE];
+#pragma unroll
+        for (int f = 0; f < NE; ++f) eL[f] = lds[f * LSTRIDE + 2 * nst];
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) {
+          CoefPreF C;
+          coef_pre_f32<FAM>(eL, P.c1_power, wf[p], C, scr[p]);
+          coef_finish_f32<FAM>(C, 1.0f / C.den, B0[p]);
+          if (P.axis_bc == ES_AXIS_SAUSAGE) { zp[p] = B0[p].a11; zq[p] = B0[p].a12; } else { zp[p] = 1.0f; zq[p] = 0.0f; }
+        }
+      }
+#define ES_F32_STEP(J, BIN, BOUT)                                                                   \
+      {                                                                                             \
+        float em[NE], e1[NE];                                                                       \
+        _Pragma("unroll") for (int f = 0; f < NE; ++f) {                                            \
+          em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                                   \
+          e1[f] = lds[f * LSTRIDE + 2 * (J)];                                                       \
+        }                                                                                           \
+        _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                           \
+          CoefPreF Cm, C1;                                                                          \
+          coef_pre_f32<FAM>(em, P.c1_power, wf[p], Cm, scr[p]);                                     \
+          coef_pre_f32<FAM>(e1, P.c1_power, wf[p], C1, scr[p]);                                     \
+          const float inv = __builtin_amdgcn_rcpf(Cm.den * C1.den);                                 \
+          CoefF Bm;                                                                                 \
+          coef_finish_f32<FAM>(Cm, C1.den * inv, Bm);                                               \
+          coef_finish_f32<FAM>(C1, Cm.den * inv, BOUT[p]);                                          \
+          rk4_step_adjoint_f32<FAM>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);              \
+        }                                                                                           \
+      }
+      // steps in pairs with the roles of B0 / B1 swapped (no coefficient copies); CH is even, so only the last chunk
+      // of an odd march has a single leading step
+      int j = nst - 1;
+      if (nst & 1) {
+        ES_F32_STEP(j, B0, B1)
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+        --j;
+      }
+      for (; j >= 1; j -= 2) {
+        ES_F32_STEP(j, B0, B1)
+        ES_F32_STEP(j - 1, B1, B0)
+        if (((j - 1) & 15) == 0) {                     // renormalise every 16 steps
+#pragma unroll
+          for (int p = 0; p < PTS; ++p) {
+            const float mag = fmaxf(fabsf(zp[p]), fabsf(zq[p]));
+            if (mag > 1.0995116e12f || (mag < 9.094947e-13f && mag > 0.0f)) {       // outside [2^-40, 2^40]
+              int ex;
+              (void)frexpf(mag, &ex);
+              zp[p] = ldexpf(zp[p], -ex);
+              zq[p] = ldexpf(zq[p], -ex);
+              zexp[p] += ex;
+            }
+          }
+        }
+      }
+#undef ES_F32_STEP
+    }
+    double bf[FamTraits<FAM>::NB], ef[NE];
+    load_base<FAM>(P, 0, bf);
+    make_entry<FAM>(bf, s, ef);
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+      const int iw = w0 + p * T + (int)threadIdx.x;
+      if (iw >= nw) continue;
+      const double w = pick_w(wv, w_mode, k, row, nw, iw);
+      const ExteriorLite X = exterior_lite(P, k, w, w);
+      // r = (r1, r2) * 2^zexp: the common factor multiplies the homogeneous part of the axis condition; its target
+      // (bc_const * xi_e, non-zero only for the twisted kink condition) is divided by it instead
+      ShootDev Pl = P;
+      Pl.bc_const = P.bc_const * ldexp(1.0, -zexp[p]);
+      const Mismatch M = boundary_algebra<FAM>(Pl, s, w, X, (double)zp[p], (double)zq[p], ef);
+      // watched terms: certain sign / certain crossing / unsure (see ScreenF)
+      const float S = F32_TAU_NODE * (float)(w * w + ef[1]);
+      const ScreenF& sc = scr[p];
+      const bool cross12 = (sc.lo1 < -S && sc.hi1 > S) || (sc.lo2 < -S && sc.hi2 > S);
+      const bool sure12 = (sc.lo1 > S || sc.hi1 < -S) && (sc.lo2 > S || sc.hi2 < -S);
+      bool crossed, node_unsure;
+      if (!TRACK) {                                     // band families: the status is exact (fp64 test on W = omega/k)
+        crossed = band_crossed(P, k, w);
+        node_unsure = !crossed && !sure12;              // an evaluated point with a coefficient close to a singular point
+      } else if (cross12) {
+        crossed = true; node_unsure = false;
+      } else if (sure12 && (FAM != FAM_CYLT || sc.c3m >= 0.0f)) {
+        crossed = (FAM == FAM_CYLT) && ((sc.or3 & ~sc.and3) < 0);
+        node_unsure = false;
+      } else {
+        crossed = false; node_unsure = true;
+      }
+      double D, rel; uint8_t st;
+      finish_point(P, M, X, crossed, D, rel, st);
+      bool unsure = false;
+      if (X.status == ES_PT_OK && crossed) {
+        unsure = TRACK && !isfinite(M.d);               // fp64 reports ES_PT_NONFINITE before ES_PT_CONTINUUM: let it decide
+      } else if (X.status == ES_PT_OK) {
+        const double scale = fmax(fabs(M.outer), fabs(M.inner));
+        unsure = node_unsure || !isfinite(M.d) || !(fabs(M.d) > F32_TAU_D * scale) ||
+                 !(fabs(M.outer) > F32_TAU_POLE * fabs(M.inner));
+      }
+      const size_t o = (size_t)row * nw + iw;
+      Dout[o] = D;
+      stout[o] = unsure ? (uint8_t)(st | F32_UNSURE) : st;
+    }
+  }
+}
+
+// cells with the UNSURE bit -> ballot masks + block counts (same layout as bracket_flag_kernel)
+__global__ __launch_bounds__(256) void unsure_flag_kernel(const uint8_t* __restrict__ st, long cells,
+                                                          uint64_t* __restrict__ masks, int* __restrict__ block_counts) {
+  __shared__ int wave_cnt[4];
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool flag = (c < cells) && (st[c] & F32_UNSURE);
+  const uint64_t m = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) {
+    masks[c >> 6] = m;
+    wave_cnt[threadIdx.x >> 6] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// ordered list of the flagged cells: (k, omega) pairs for the fp64 point kernel and the cell index to scatter back to
+__global__ __launch_bounds__(256) void unsure_gather_kernel(const double* __restrict__ kv, const double* __restrict__ wv,
+                                                            int nw, int w_mode, long cells,
+                                                            const uint64_t* __restrict__ masks,
+                                                            const int* __restrict__ block_off, double* __restrict__ pk,
+                                                            double* __restrict__ pw, long* __restrict__ pcell) {
+  const long c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cells) return;
+  if (!((masks[c >> 6] >> (c & 63)) & 1ull)) return;
+  const int pos = es_cell_rank(masks, block_off, c);
+  const long row = c / nw;
+  const int j = (int)(c - row * nw);
+  const double k = kv[row];
+  pk[pos] = k;
+  pw[pos] = pick_w(wv, w_mode, k, (int)row, nw, j);
+  pcell[pos] = c;
+}
+
+__global__ __launch_bounds__(256) void scatter_points_kernel(const long* __restrict__ pcell, const double* __restrict__ pD,
+                                                             const uint8_t* __restrict__ pst, int n,
+                                                             double* __restrict__ D, uint8_t* __restrict__ st) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  D[pcell[i]] = pD[i];
+  st[pcell[i]] = pst[i];
+}
+
+// both ends of every bracket as (k, omega) pairs: [0, n) lower ends, [n, 2n) upper ends
+__global__ __launch_bounds__(256) void bracket_ends_kernel(es_root_table tab, int n, double* __restrict__ pk,
+                                                           double* __restrict__ pw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  pk[i] = tab.d_k[i]; pk[n + i] = tab.d_k[i];
+  pw[i] = tab.d_w_lo[i]; pw[n + i] = tab.d_w_hi[i];
+}
+
+// fp64 values at the bracket ends replace the screening values the refinement starts from; a bracket whose fp64 ends do
+// not change sign (or are not both ES_PT_OK) would be a failure of the screening bound: counted, never hidden
+__global__ __launch_bounds__(256) void bracket_ends_store_kernel(const double* __restrict__ pD, const uint8_t* __restrict__ pst,
+                                                                 int n, double* __restrict__ d_lo, double* __restrict__ d_hi,
+                                                                 int* __restrict__ violations) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double a = pD[i], b = pD[n + i];
+  d_lo[i] = a;
+  d_hi[i] = b;
+  if (!(pst[i] == ES_PT_OK && pst[n + i] == ES_PT_OK && a * b < 0.0)) atomicAdd(violations, 1);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -490,11 +822,16 @@ int launch_points(es_context* ctx, const es_problem* prob, const double* d_k, co
 template <int FAM>
 int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const double* d_lo,
                   const double* d_hi, int n, int n_bisect, double tol) {
-  // 9-section rounds equivalent to n_bisect halvings: 9^R >= 2^n_bisect
+  // (LANES+1)-section rounds equivalent to n_bisect halvings: (LANES+1)^R >= 2^n_bisect
+  const int sections = refine_sections(n);
   int rounds = 0;
-  for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= 9.0) ++rounds;
-  hipLaunchKernelGGL((refine_kernel<FAM>), dim3((n + 7) / 8), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, d_hi,
-                     n, rounds, ES_REFINE_POLISH, tol);
+  for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
+  if (sections == 17)
+    hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 3) / 4), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, d_hi,
+                       n, rounds, ES_REFINE_POLISH, tol);
+  else
+    hipLaunchKernelGGL((refine_kernel<FAM, 8>), dim3((n + 7) / 8), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, d_hi,
+                       n, rounds, ES_REFINE_POLISH, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
@@ -756,6 +1093,167 @@ extern "C" int es_shoot_find_roots(es_context* ctx, const es_problem* prob, cons
     }
 #undef CALL_REF
     if (rr) return rr;
+  }
+  return total > table->capacity ? ES_ERR_CAPACITY : ES_SUCCESS;
+}
+
+
+// ---- fp32 screening + fp64 refinement (configs[4]) ---------------------------------------------------------------------
+namespace {
+template <int FAM>
+int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
+                    int w_mode, double* d_D, uint8_t* d_status) {
+  if constexpr (FAM == FAM_CYL0 || FAM == FAM_CYLT) {
+    constexpr int PTS = 4;
+    int T = ((nw + PTS - 1) / PTS + 63) / 64 * 64;
+    if (T < 64) T = 64;
+    if (T > 256) T = 256;
+    const long tiles = (long)nk * ((nw + T * PTS - 1) / (T * PTS));
+    const int grid = (int)(tiles < (1L << 22) ? tiles : (1L << 22));
+    const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
+    // register caps: 128 VGPRs (4 waves per SIMD) for the untwisted family, 168 (3 waves) for the twisted one
+    if constexpr (FAM == FAM_CYL0) {
+      if (bands)
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 4>), dim3(grid), dim3(T), 0, ctx->stream,
+                           prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      else
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 4>), dim3(grid), dim3(T), 0, ctx->stream,
+                           prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+    } else {
+      // measured on configs[4] (1024^2, N = 2000): 4 points per lane at 2 waves per SIMD (no spills) 5.7 ms; the same
+      // capped at 168 registers (3 waves) spills inside the loop, 16.0 ms; 2 points per lane at 4 waves 6.1 ms; fp64 9.4 ms
+      int variant = 1;
+      if (const char* ev = getenv("ES_F32_VARIANT")) variant = atoi(ev);        // tuning aid
+      if (variant == 1) {
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 2>), dim3(grid), dim3(T), 0, ctx->stream,
+                           prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      } else if (variant == 2) {
+        int T2 = ((nw + 1) / 2 + 63) / 64 * 64;
+        if (T2 < 64) T2 = 64;
+        if (T2 > 256) T2 = 256;
+        const long tiles2 = (long)nk * ((nw + T2 * 2 - 1) / (T2 * 2));
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, 2, 256, true, 4>), dim3((int)(tiles2 < (1L << 22) ? tiles2 : (1L << 22))),
+                           dim3(T2), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      } else {
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 3>), dim3(grid), dim3(T), 0, ctx->stream,
+                           prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      }
+    }
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_SUCCESS;
+  } else {
+    ctx->last_error = "fp32 screening is implemented for the cylinder families";
+    return ES_ERR_UNSUPPORTED;
+  }
+}
+
+template <int FAM>
+int points_into(es_context* ctx, const es_problem* prob, const double* pk, const double* pw, int n, double* pD,
+                uint8_t* pst) {
+  return launch_points<FAM>(ctx, prob, pk, pw, n, pD, nullptr, pst);
+}
+}  // namespace
+
+extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                         const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
+                                         double* d_D, uint8_t* d_status, es_root_table* table, int* h_count,
+                                         int* h_stats) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, table && h_count, "null pointer");
+  ES_REQUIRE(ctx, nk >= 0 && nw >= 0 && n_bisect >= 0 && table->capacity >= 0, "negative size");
+  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  *h_count = 0;
+  if (h_stats) h_stats[0] = h_stats[1] = h_stats[2] = 0;
+  const long cells = (long)nk * nw;
+  if (cells == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  ES_REQUIRE(ctx, table->capacity == 0 || (table->d_k && table->d_w && table->d_w_lo && table->d_w_hi &&
+                                           table->d_resid && table->d_row && table->d_flag),
+             "null root table arrays");
+  const int fam = prob->dev.family;
+  if (fam != FAM_CYL0 && fam != FAM_CYLT) {
+    ctx->last_error = "fp32 screening is implemented for the cylinder families";
+    return ES_ERR_UNSUPPORTED;
+  }
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // 1. fp32 screening pass
+  rc = (fam == FAM_CYL0) ? launch_grid_f32<FAM_CYL0>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status)
+                         : launch_grid_f32<FAM_CYLT>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+  if (rc) return rc;
+  // 2. unsure points -> fp64
+  rc = es_ensure_scan_scratch(ctx, (size_t)cells);
+  if (rc) return rc;
+  const int nblocks = (int)((cells + 255) / 256);
+  hipLaunchKernelGGL(unsure_flag_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_status, cells, ctx->d_masks,
+                     ctx->d_block_counts);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  int n_unsure = 0;
+  rc = es_scan_block_counts(ctx, nblocks, &n_unsure);
+  if (rc) return rc;
+  auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  auto carve = [&](size_t n, double*& pk, double*& pw, double*& pD, long*& pcell, uint8_t*& pst) -> int {
+    const size_t bd = align(n * sizeof(double));
+    int r = es_ensure_scratch(ctx, 4 * bd + align(n));
+    if (r) return r;
+    char* b = (char*)ctx->d_scratch;
+    pk = (double*)b; pw = (double*)(b + bd); pD = (double*)(b + 2 * bd); pcell = (long*)(b + 3 * bd);
+    pst = (uint8_t*)(b + 4 * bd);
+    return ES_SUCCESS;
+  };
+  double *pk, *pw, *pD; long* pcell; uint8_t* pst;
+  if (n_unsure > 0) {
+    rc = carve((size_t)n_unsure, pk, pw, pD, pcell, pst);
+    if (rc) return rc;
+    hipLaunchKernelGGL(unsure_gather_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w, nw, w_mode, cells,
+                       ctx->d_masks, ctx->d_block_counts, pk, pw, pcell);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    rc = (fam == FAM_CYL0) ? points_into<FAM_CYL0>(ctx, prob, pk, pw, n_unsure, pD, pst)
+                           : points_into<FAM_CYLT>(ctx, prob, pk, pw, n_unsure, pD, pst);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scatter_points_kernel, dim3((n_unsure + 255) / 256), dim3(256), 0, ctx->stream, pcell, pD, pst,
+                       n_unsure, d_D, d_status);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+  }
+  // 3. brackets on the merged array (signs and statuses are now those of the fp64 path)
+  hipLaunchKernelGGL(bracket_flag_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_D, d_status, nw, cells,
+                     ctx->d_masks, ctx->d_block_counts);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  int total = 0;
+  rc = es_scan_block_counts(ctx, nblocks, &total);
+  if (rc) return rc;
+  *h_count = total;
+  const int n = total < table->capacity ? total : table->capacity;
+  int violations = 0;
+  if (n > 0) {
+    hipLaunchKernelGGL(bracket_emit_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w, nw, w_mode, cells,
+                       d_D, ctx->d_masks, ctx->d_block_counts, *table, table->d_w, table->d_resid);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    // 4. both ends of every bracket in fp64: the refinement starts from the numbers of the fp64 path
+    rc = carve((size_t)2 * n, pk, pw, pD, pcell, pst);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bracket_ends_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, *table, n, pk, pw);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    rc = (fam == FAM_CYL0) ? points_into<FAM_CYL0>(ctx, prob, pk, pw, 2 * n, pD, pst)
+                           : points_into<FAM_CYLT>(ctx, prob, pk, pw, 2 * n, pD, pst);
+    if (rc) return rc;
+    ES_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(bracket_ends_store_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pD, pst, n,
+                       table->d_w, table->d_resid, ctx->d_total);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    ES_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // 5. fp64 refinement
+    rc = (fam == FAM_CYL0) ? launch_refine<FAM_CYL0>(ctx, prob, *table, table->d_w, table->d_resid, n, n_bisect, tol_percent)
+                           : launch_refine<FAM_CYLT>(ctx, prob, *table, table->d_w, table->d_resid, n, n_bisect, tol_percent);
+    if (rc) return rc;
+    ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    violations = *ctx->h_total;
+  }
+  if (h_stats) { h_stats[0] = n_unsure; h_stats[1] = 2 * n; h_stats[2] = violations; }
+  if (violations != 0) {
+    ctx->last_error = "fp32 screening: a bracket was not confirmed by the fp64 values at its ends";
+    return ES_ERR_SCREENING;
   }
   return total > table->capacity ? ES_ERR_CAPACITY : ES_SUCCESS;
 }

@@ -88,7 +88,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
     if (c == nchunks - 1) {                            // last node: start vector of the march
 #pragma unroll
       for (int f = 0; f < NB; ++f) b[f] = sb[2 * nst * NB + f];
-      make_entry<FAM>(b, s, e);
+      make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
       coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
       adjoint_start(P, B0, zp, zq);
     }
@@ -96,12 +96,12 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
       Coef Bm, B1;
 #pragma unroll
       for (int f = 0; f < NB; ++f) b[f] = sb[(2 * j + 1) * NB + f];
-      make_entry<FAM>(b, s, e);
+      make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
 #pragma unroll
       for (int f = 0; f < NB; ++f) b[f] = sb[2 * j * NB + f];
-      make_entry<FAM>(b, s, e2);
+      make_entry<FAM, fam_scaled<FAM>()>(b, s, e2);
       coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
-      rk4_step_adjoint<FamTraits<FAM>::SHAPE>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+      adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
       B0 = B1;
     }
   }

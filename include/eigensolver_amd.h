@@ -32,7 +32,8 @@ enum {
   ES_ERR_CAPACITY = 3,     /* caller-provided output buffer too small (count is still returned) */
   ES_ERR_NO_DEVICE = 4,
   ES_ERR_UNSUPPORTED = 5,
-  ES_ERR_EVAL_CAP = 6      /* es_worker_run: a task exceeded its evaluation bound; its root list is incomplete   */
+  ES_ERR_EVAL_CAP = 6,     /* es_worker_run: a task exceeded its evaluation bound; its root list is incomplete   */
+  ES_ERR_SCREENING = 7     /* es_shoot_find_roots_mixed: an fp32-screened bracket was not confirmed in fp64      */
 };
 
 /* ---- per-point status written next to D(k, omega) ------------------------------------------------------
@@ -194,6 +195,23 @@ typedef struct es_root_table {
 int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                         const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,
                         int n_bisect, double tol_percent, es_root_table* table, int* h_count);
+
+/* Mixed-precision grid search (BASELINE.json configs[4]: "fp32 bracket + fp64 refine"; the reference itself is fp64
+ * throughout).  Same result as es_shoot_eval_grid + es_shoot_find_roots -- identical bracket set, bit-identical root
+ * table -- for the cylinder families (ES_GEOM_CYLINDER, ES_GEOM_CYLINDER_TWIST):
+ *   1. the (k, omega) grid is marched in fp32 (exterior and boundary algebra in fp64); points at which fp32 cannot vouch
+ *      for the sign of D or for the status (|D| < 5e-2 of max(|outer|, |inner|), a pole of D nearby, a coefficient within
+ *      1e-3 of a singular point at some node, non-finite result) are marked and re-evaluated in fp64;
+ *   2. brackets are detected on the merged array, BOTH ends of every bracket are re-evaluated in fp64 (the determinant
+ *      signs at bracket endpoints are fp64 signs) -- a bracket these values do not confirm makes the call return
+ *      ES_ERR_SCREENING;
+ *   3. refinement and classification in fp64 exactly as es_shoot_find_roots.
+ * d_D / d_status (nk x nw, caller allocated) receive the screening result: fp64 values at the re-evaluated points, fp32-
+ * accurate values elsewhere (not defined at ES_PT_CONTINUUM points of the band families).
+ * h_stats (optional, 3 ints): fp64 re-evaluations of unsure grid points, of bracket ends, unconfirmed brackets. */
+int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                              const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
+                              double* d_D, uint8_t* d_status, es_root_table* table, int* h_count, int* h_stats);
 
 /* ========================================================================================================
  * (3) The reference worker itself: kink(wavenumber, kink_ws, kink_ks, freq) / sausage(...) for a batch of

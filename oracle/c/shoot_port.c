@@ -237,6 +237,9 @@ static void make_entry(const port_problem* P, int pt, const kscal* s, double* e)
       e[0] = s->k * b[0]; e[1] = wA2; e[2] = wA2 * b[2]; e[3] = b[3];
       /* a21 = -r C2/(rho S t1 t2) = -B + (lambda t2 + c0)/(t1 t2), lambda = g - B (wA^2 + wc^2), c0 = -B wc^4 */
       e[4] = -b[4]; e[5] = g - b[4] * (e[1] + e[2]); e[6] = -(b[4] * (e[2] * e[2]));
+      /* scaled-coefficient form of the untwisted cylinder (make_entry<FAM_CYL0, true> of the HIP code): the entries
+       * that become a12 and a21 carry h/2 */
+      { const double h2 = 0.5 * P->h; e[3] *= h2; e[4] *= h2; e[5] *= h2; e[6] *= h2; }
     } break;
     case 1: {
       double r = b[0], invr = b[1], rho = b[2], S = b[3];
@@ -334,6 +337,19 @@ static inline void rhs_t(int diag, const coef* A, double p, double q, double* kp
   if (diag) { *kp = fma(A->a11, p, A->a21 * q); *kq = fma(A->a22, q, A->a12 * p); }
   else { *kp = A->a21 * q; *kq = A->a12 * p; }
 }
+/* rk4_step_adjoint_scaled0 of the HIP code: off-diagonal A pre-multiplied by h/2 */
+static void rk4_adjoint_scaled0(double* p, double* q, const coef* B0, const coef* Bm, const coef* B1) {
+  const double tp1 = fma(B0->a21, *q, *p), tq1 = fma(B0->a12, *p, *q);
+  const double tp2 = fma(Bm->a21, tq1, *p), tq2 = fma(Bm->a12, tp1, *q);
+  const double am2 = Bm->a21 + Bm->a21, bm2 = Bm->a12 + Bm->a12;
+  const double tp3 = fma(am2, tq2, *p), tq3 = fma(bm2, tp2, *q);
+  const double sp = fma(2.0, tp2, tp1 + tp3) - *p;
+  const double sq = fma(2.0, tq2, tq1 + tq3) - *q;
+  const double third = 1.0 / 3.0;
+  *p = fma(B1->a21, tq3, sp) * third;
+  *q = fma(B1->a12, tp3, sq) * third;
+}
+
 static void rk4_adjoint(int diag, double* p, double* q, const coef* B0, const coef* Bm, const coef* B1, double h,
                         double h2, double h6, double h3) {
   double k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
@@ -449,7 +465,8 @@ static int port_eval_core(const port_problem* P, double k, double w, double w_cs
     make_entry(P, 2 * j + 1, &s, e);
     make_entry(P, 2 * j, &s, e2);
     coefficients2(P, e, e2, &s, w, &Bm, &B1, tp);
-    rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
+    if (P->family == 0) rk4_adjoint_scaled0(&zp, &zq, &B0, &Bm, &B1);
+    else rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
     B0 = B1;
   }
   exterior X = (P->family <= 1) ? ext_cyl(P, k, w, w_cst) : ext_slab(P, k, w);
@@ -542,7 +559,9 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
   long n = count < capacity ? count : capacity;
   int rounds = 0;
   const int polish = 2;
-  for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= 9.0) ++rounds;
+  /* (LANES+1)-section as the HIP refine_kernel: 17 sections (16 lanes per bracket) up to 32768 brackets, 9 beyond */
+  const int sections = (n <= 32768) ? 17 : 9;
+  for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -552,18 +571,19 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
     double kk = k[row], lo = pick_w(w, w_mode, kk, row, nw, j), hi = pick_w(w, w_mode, kk, row, nw, j + 1);
     double flo = D[c], fhi = D[c + 1], d = NAN, r = NAN;
     int s = ES_PT_NONFINITE;
-    /* 9-section rounds, as the HIP refine_kernel: points lo + (hi-lo)*(j+1)/9, first sign change from the left */
+    /* multi-section rounds, as the HIP refine_kernel: points lo + (hi-lo)*(j+1)/sections, first sign change from the left */
+    const int L = sections - 1;
     for (int it = 0; it < rounds; ++it) {
-      double x[8], dv[8];
-      int first = 8;
-      for (int j = 0; j < 8; ++j) {
-        x[j] = lo + (hi - lo) * ((double)(j + 1) / 9.0);
+      double x[16], dv[16];
+      int first = L;
+      for (int j = 0; j < L; ++j) {
+        x[j] = lo + (hi - lo) * ((double)(j + 1) / (double)sections);
         port_eval(P, kk, x[j], &dv[j], &r);
       }
-      for (int j = 0; j < 8; ++j) if (dv[j] * flo < 0.0) { first = j; break; }
+      for (int j = 0; j < L; ++j) if (dv[j] * flo < 0.0) { first = j; break; }
       double nlo = lo, nflo = flo;
       if (first > 0) { nlo = x[first - 1]; nflo = (dv[first - 1] == dv[first - 1]) ? dv[first - 1] : flo; }
-      if (first < 8) { hi = x[first]; fhi = dv[first]; }
+      if (first < L) { hi = x[first]; fhi = dv[first]; }
       lo = nlo; flo = nflo;
     }
     /* regula-falsi polish (ES_REFINE_POLISH = 2 steps in the HIP kernel) */

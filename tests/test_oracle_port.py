@@ -57,3 +57,27 @@ def test_continuum_bands_equal_per_node_tracking(monkeypatch):
         assert np.array_equal(Db[stb == 0], Dt[stt == 0])
         n_cont += int((stb == 3).sum())
     assert n_cont > 1000
+
+
+def test_numpy_grid_matches_port():
+    """oracle/grid_numpy.py (vectorised NumPy restatement timed by bench.py as the second CPU baseline) against the C
+    port on the bench workload in small: identical statuses, |dD| <= 1e-10 of the scale (no fma in NumPy)."""
+    import numpy as np
+    from eigensolver_amd import equilibrium as q, shooting as s
+    from oracle.grid_numpy import CylinderGrid
+    from oracle.port import PortProblem
+    for eq, mode, m in ((q.CylinderFlow(U_i0=0.7, width=0.9, n_nodes=300), "kink", 1),
+                        (q.CylinderFlow(U_i0=0.7, width=0.9, n_nodes=300), "sausage", 0),
+                        (q.CylinderDensity(width=0.95, n_nodes=300), "kink", 3)):
+        d, prof = s.make_desc(eq, mode, m)
+        desc = {f[0]: getattr(d, f[0]) for f in d._fields_}
+        port = PortProblem(desc, prof)
+        k = np.array([0.05, 0.7, 2.1, 3.9])
+        W = 0.9 + (np.arange(200) + 0.5) * (4.1 / 200)
+        Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=2)
+        Dn, reln, stn = CylinderGrid(desc, {a: np.asarray(v) for a, v in prof.items()}).eval_grid(k, W)
+        assert np.array_equal(stp, stn)
+        ok = stp == 0
+        assert ok.sum() > 200
+        scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
+        assert np.max(np.abs(Dp[ok] - Dn[ok]) / scale) < 1e-10
