@@ -179,9 +179,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("strong", "weak-m"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--march-continuum", action="store_true",
-                    help="march the points inside continuum bands too (round-1 behaviour); default: "
-                         "ES_EVAL_SKIP_CONTINUUM, they get D = NaN, are not marched and are NOT counted in `value`")
+    ap.add_argument("--skip-continuum", action="store_true",
+                    help="time the steps with ES_EVAL_SKIP_CONTINUUM: points inside continuum bands get D = NaN, are not "
+                         "marched and are NOT counted in `value`.  Default: every grid point is marched, as the reference "
+                         "evaluates every point; the skip mode is then measured after the timed region and reported "
+                         "under config.skip_continuum_mode")
     ap.add_argument("--dump-roots", default=None, help="write the merged root table of the last step to this .npy")
     ap.add_argument("--workload", choices=("config3", "config4"), default="config3",
                     help="config3 (default, the headline): BASELINE.json configs[3]; config4: configs[4], Cylinder / "
@@ -235,10 +237,12 @@ def main():
     nk_local = int(k.numel())
     table = prob.alloc_root_table(1 << 18)
 
+    skip = bool(a.skip_continuum)
+
     def step(ev=None):
         if ev is not None:
             ev[0].record()
-        D_, st = prob.eval_grid(k, W, skip_continuum=not a.march_continuum)
+        D_, st = prob.eval_grid(k, W, skip_continuum=skip)
         if ev is not None:
             ev[1].record()
         roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
@@ -261,12 +265,31 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
 
+    # the other mode of the grid evaluation, a few steps outside the timed region (N = 1 only): reported, never `value`
+    other = None
+    if world == 1:
+        st_main = st
+        skip = not skip
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_other = max(3, min(10, a.steps))
+        for _ in range(n_other):
+            r_o, nbr_o, _, st_o = step()
+        torch.cuda.synchronize()
+        dt_o = (time.perf_counter() - t1) / n_other
+        n_eval_o = int((st_o != 3).sum()) if skip else nk_local * NW
+        other = {"ms_per_step": dt_o * 1e3, "roots_per_s": int((r_o["flag"] == 1).sum()) / dt_o,
+                 "grid_points_evaluated_per_step": n_eval_o, "brackets_per_step": nbr_o,
+                 "det_evals_per_s": (n_eval_o + nbr_o * refine_plan(nbr_o)[2]) / dt_o, "steps": n_other}
+        skip = not skip
+        st = st_main
     cdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     hist = torch.bincount(st.reshape(-1).to(torch.int64), minlength=4)[:4].to(torch.float64).to(cdev)
     n_acc = int((roots["flag"] == 1).sum())
     # grid points one step really evaluates: all of them, or (default) those outside the continuum bands
-    n_eval_local = nk_local * NW if a.march_continuum else int((st != 3).sum())
+    n_eval_local = int((st != 3).sum()) if skip else nk_local * NW
     counts = torch.tensor([float(nbr), float(n_acc), float(n_eval_local)], dtype=torch.float64, device=cdev)
     grid_ms_t = torch.tensor([float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -323,13 +346,14 @@ def main():
                        "gathered_root_records": int(merged.shape[0]) if (world > 1 and merged is not None) else 0,
                        "grid_point_status_fractions": frac,
                        "grid_points_evaluated_per_step": grid_points,
-                       "status_note": ("every grid point is marched and counted in `value`; continuum points (Omega^2 "
-                                       "crosses omega_A^2(r) or omega_c^2(r) inside the tube) are evaluated as the "
-                                       "reference does but never bracketed") if a.march_continuum else
-                                      ("ES_EVAL_SKIP_CONTINUUM: points inside a continuum band (Omega^2 crosses "
-                                       "omega_A^2(r) or omega_c^2(r) inside the tube; the reference returns integrator "
-                                       "noise there and the grid search never brackets them) get D = NaN, are NOT "
-                                       "marched and are NOT counted in `value`; --march-continuum restores round 1"),
+                       "continuum_points": ("ES_EVAL_SKIP_CONTINUUM: points inside a continuum band (Omega^2 crosses "
+                                            "omega_A^2(r) or omega_c^2(r) inside the tube; the reference returns integrator "
+                                            "noise there and the grid search never brackets them) get D = NaN, are NOT "
+                                            "marched and are NOT counted in `value`") if skip else
+                                           ("every grid point is marched and counted in `value`, as the reference evaluates "
+                                            "every point; the continuum fraction of grid_point_status_fractions is never "
+                                            "bracketed"),
+                       ("all_points_marched_mode" if skip else "skip_continuum_mode"): other,
                        "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": "shoot_grid_kernel<FAM_CYL0>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -382,33 +406,47 @@ def main_config4(a):
     k = torch.linspace(0.25, 4.0, n, dtype=torch.float64, device=dev)
     W = 0.7 + (torch.arange(n, dtype=torch.float64, device=dev) + 0.5) * ((1.45 - 0.7) / n)
     orders = D.tile_modes(list(range(11)), rank, world)
-    probs = []
+    # one library context = one HIP stream per azimuthal order, each driven by its own host thread (ctypes releases the
+    # GIL): the orders are independent problems and the refinement / re-evaluation kernels of ONE order cannot fill the
+    # chip (a few thousand brackets -> about one wave per SIMD), so their launches overlap across streams
+    from concurrent.futures import ThreadPoolExecutor
+    work = []
     for m in orders:
         eq = q.CylinderRotation(v_twist=0.1, power=1.0, r_axis=0.01 if m == 0 else 0.001)
-        probs.append((m, ShootProblem(eq, "sausage" if m == 0 else "kink", m=m, ctx=ctx)))
-    table = probs[0][1].alloc_root_table(1 << 17) if probs else None
+        stream = torch.cuda.Stream(device=dev)
+        cx = _lib.Context(local_rank, stream=stream)
+        prob = ShootProblem(eq, "sausage" if m == 0 else "kink", m=m, ctx=cx)
+        with torch.cuda.stream(stream):
+            table = prob.alloc_root_table(1 << 15)
+        work.append((m, prob, stream, table))
+    pool = ThreadPoolExecutor(max_workers=max(1, len(work)))
     rows_t = torch.arange(n, device=dev)
     mixed = a.precision == "mixed"
+    torch.cuda.synchronize()
 
-    def step():
-        tot_br = tot_acc = tot_re = 0
-        bufs = []
-        for m, prob in probs:
+    def one_order(item):
+        m, prob, stream, table = item
+        with torch.cuda.stream(stream):
             if mixed:
                 roots, nbr, _, _, stats = prob.find_roots_mixed(k, W, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
-                tot_re += stats[0] + stats[1]
+                nre = stats[0] + stats[1]
             else:
                 D_, st = prob.eval_grid(k, W)
                 roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
-            tot_br += nbr
-            tot_acc += int((roots["flag"] == 1).sum())
-            if world > 1:
-                bufs.append(D.pack_fixed(roots, nbr, m, rows_t, 1 << 13))
+                nre = 0
+            nacc = int((roots["flag"] == 1).sum())
+            buf = D.pack_fixed(roots, nbr, m, rows_t, 1 << 13) if world > 1 else None
+            stream.synchronize()
+        return nbr, nacc, nre, buf
+
+    def step():
+        res = list(pool.map(one_order, work))
         if world > 1:                                  # one all-gather per step (ranks own 1 or 2 orders: pad to 2)
+            bufs = [r[3] for r in res]
             while len(bufs) < 2:
-                bufs.append(torch.zeros_like(bufs[0]) if bufs else torch.zeros(((1 << 13) + 1, D.N_FIELDS), dtype=torch.float64, device=dev))
+                bufs.append(torch.zeros(((1 << 13) + 1, D.N_FIELDS), dtype=torch.float64, device=dev))
             D.gather_fixed(torch.cat(bufs, dim=0), world)
-        return tot_br, tot_acc, tot_re
+        return sum(r[0] for r in res), sum(r[1] for r in res), sum(r[2] for r in res)
 
     for _ in range(a.warmup):
         step()

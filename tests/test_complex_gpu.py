@@ -140,3 +140,28 @@ def test_unsupported_geometry_is_refused(es_ctx):
     with pytest.raises(_lib.EsError):
         s.eval_points("kink", 1.0, np.array([0.5 + 0.1j]))
     s.close()
+
+
+def test_gpu_reproduces_the_sfx_kink_worker_at_real_frequencies(es_ctx):
+    """ES_CX_SFX at Im(omega) = 0 against the numbers the reference's complex worker itself produced there
+    (tests/golden/trace_SFX_kink_real.json, see tests/test_oracle_complex.py): D_c = d_ref / V_e(-1) within LSODA's
+    tolerance, Im D_c = 0.  (Off the real axis: parity unpinned)"""
+    import json
+    import os
+    from eigensolver_amd import SlabComplexFlow
+    from tests.test_oracle_complex import sfx_bound
+    tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_SFX_kink_real.json")))
+    n = 0
+    for s in tr["sets"]:
+        sol = SlabComplexFlow(U_i0=s["U_i0"], width=s["width"], variant="sfx", ctx=es_ctx)
+        ev = [e for e in s["evals"] if e["ier"] == 1 and abs(e["ext_value"]) >= 1e-5]
+        w = np.array([complex(e["w"], 0.0) for e in ev])
+        D, st, rel = (t.cpu().numpy() for t in sol.eval_points("kink", s["k"], w))
+        assert np.all(st == 0)
+        for e, d, r in zip(ev, D, rel):
+            scale = abs(d) * 100.0 / r
+            assert abs(d.imag) <= 1e-12 * abs(d)
+            assert abs(d.real - e["d"] / e["ext_value"]) / scale < sfx_bound(e["ext_value"]), (s["k"], e["w"], d)
+            n += 1
+        sol.close()
+    assert n >= 32

@@ -105,3 +105,40 @@ def closed_form_root(P, k, guess):
         if abs(w1 - w0) < 1e-15:
             break
     return w1
+
+
+# ---- the reference's own evaluation: SF-X `kink` executed in the build container at Im(omega) = 0 ----------------
+SFX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_SFX_kink_real.json")))
+
+
+def sfx_bound(A):
+    """LSODA's tolerance on the reference's side: interior error 40 * atol / A for a solution of amplitude A (as for the
+    real workers, tests/test_oracle_golden.py) on top of the exterior's own error (started at 1e-8 < atol; 2e-3 of the
+    scale covers every traced evaluation of amplitude A > 1e-5)."""
+    return max(2e-3, 40 * 1.5e-8 / abs(A))
+
+
+def test_sfx_kink_worker_trace_at_real_frequencies():
+    """tests/golden/trace_SFX_kink_real.json (tools/gen_golden_sfx.py): 48 mismatch values (35 of them with an exterior amplitude above 1e-5, the ones compared) the reference's complex
+    worker `kink` (SF-X:737) computed at real omega -- uniform flow as checked in (U_i0 = 1.4) and the Gaussian profile
+    (dx = 0.9, U_i0 = 0.2; with U_i0 = 1.4 every evanescent real frequency lies in the flow continuum).  The oracle's
+    variant "sfx" (D of SF-X:940, total pressure with the U' term SF-X:955-960) reproduces them to LSODA's tolerance:
+    this pins the complex path's FORMULAS to the reference's outputs on the real axis.  Off the real axis SF-X mixes
+    real and imaginary parts and `sausage` / `locate_*` raise ValueError: parity unpinned there."""
+    n = 0
+    worst = 0.0
+    for s in SFX["sets"]:
+        P = ComplexFlowSlab(width=s["width"], U_i0=s["U_i0"], mode="kink", variant="sfx")
+        for e in s["evals"]:
+            A = e["ext_value"]
+            if e["ier"] != 1 or abs(A) < 1e-5:
+                continue
+            d, rel, st = P.eval_rk4(s["k"], complex(e["w"], 0.0))
+            assert st[0] == 0 and abs(d[0].imag) <= 1e-12 * abs(d[0])
+            scale = abs(d[0]) * 100.0 / rel[0]
+            err = abs(d[0].real - e["d"] / A) / scale
+            worst = max(worst, err)
+            assert err < sfx_bound(A), (s["width"], s["k"], e["w"], d[0], e["d"] / A, err)
+            assert (d[0].real > 0) == (e["d"] / A > 0) or abs(d[0].real) < sfx_bound(A) * scale
+            n += 1
+    assert n >= 32 and worst < 5e-3, (n, worst)
