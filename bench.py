@@ -185,6 +185,9 @@ def main():
                          "evaluates every point; the skip mode is then measured after the timed region and reported "
                          "under config.skip_continuum_mode")
     ap.add_argument("--dump-roots", default=None, help="write the merged root table of the last step to this .npy")
+    ap.add_argument("--no-extra-mode", action="store_true",
+                    help="do not measure the other continuum mode after the timed region (profiling runs: keeps the "
+                         "per-kernel counters of one mode apart)")
     ap.add_argument("--workload", choices=("config3", "config4"), default="config3",
                     help="config3 (default, the headline): BASELINE.json configs[3]; config4: configs[4], Cylinder / "
                          "rotational flow, m = 0..10, fp32 bracket + fp64 refine (a second, never the headline, line)")
@@ -267,7 +270,7 @@ def main():
 
     # the other mode of the grid evaluation, a few steps outside the timed region (N = 1 only): reported, never `value`
     other = None
-    if world == 1:
+    if world == 1 and not a.no_extra_mode:
         st_main = st
         skip = not skip
         step()

@@ -144,13 +144,13 @@ def test_unsupported_geometry_is_refused(es_ctx):
 
 def test_gpu_reproduces_the_sfx_kink_worker_at_real_frequencies(es_ctx):
     """ES_CX_SFX at Im(omega) = 0 against the numbers the reference's complex worker itself produced there
-    (tests/golden/trace_SFX_kink_real.json, see tests/test_oracle_complex.py): D_c = d_ref / V_e(-1) within LSODA's
+    (tests/golden/sfx_kink_real_axis.json, see tests/test_oracle_complex.py): D_c = d_ref / V_e(-1) within LSODA's
     tolerance, Im D_c = 0.  (Off the real axis: parity unpinned)"""
     import json
     import os
     from eigensolver_amd import SlabComplexFlow
     from tests.test_oracle_complex import sfx_bound
-    tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_SFX_kink_real.json")))
+    tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sfx_kink_real_axis.json")))
     n = 0
     for s in tr["sets"]:
         sol = SlabComplexFlow(U_i0=s["U_i0"], width=s["width"], variant="sfx", ctx=es_ctx)

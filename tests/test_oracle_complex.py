@@ -108,7 +108,7 @@ def closed_form_root(P, k, guess):
 
 
 # ---- the reference's own evaluation: SF-X `kink` executed in the build container at Im(omega) = 0 ----------------
-SFX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trace_SFX_kink_real.json")))
+SFX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sfx_kink_real_axis.json")))
 
 
 def sfx_bound(A):
@@ -119,7 +119,7 @@ def sfx_bound(A):
 
 
 def test_sfx_kink_worker_trace_at_real_frequencies():
-    """tests/golden/trace_SFX_kink_real.json (tools/gen_golden_sfx.py): 48 mismatch values (35 of them with an exterior amplitude above 1e-5, the ones compared) the reference's complex
+    """tests/golden/sfx_kink_real_axis.json (tools/gen_golden_sfx.py): 48 mismatch values (35 of them with an exterior amplitude above 1e-5, the ones compared) the reference's complex
     worker `kink` (SF-X:737) computed at real omega -- uniform flow as checked in (U_i0 = 1.4) and the Gaussian profile
     (dx = 0.9, U_i0 = 0.2; with U_i0 = 1.4 every evanescent real frequency lies in the flow continuum).  The oracle's
     variant "sfx" (D of SF-X:940, total pressure with the U' term SF-X:955-960) reproduces them to LSODA's tolerance:

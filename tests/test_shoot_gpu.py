@@ -281,7 +281,7 @@ def test_gpu_accepts_stored_reference_roots(es_ctx, tag):
         D, st, rel = gp.eval_points(k, w, want_rel=True)
         rel = rel.cpu().numpy()
         frac = float(np.mean(rel < tol))
-        assert frac >= S.floor_of(tag, mode), (tag, mode, frac)
+        assert frac >= S.floor_of(tag, mode) - 0.05, (tag, mode, frac)       # committed measured fraction, max drop 0.05
         Dp, relp, stp = cases.port_problem(eq, mode).eval_points(k, w, nthreads=8)
         assert np.array_equal(st.cpu().numpy(), stp)
         decided = np.abs(relp - tol) > 1e-6 * tol                  # points not sitting on the threshold itself

@@ -1,6 +1,6 @@
 """Trace of the reference's complex-frequency worker (SF-X) where it is self-consistent: Im(omega) = 0.
 
-    python tools/gen_golden_sfx.py      ->  tests/golden/trace_SFX_kink_real.json
+    python tools/gen_golden_sfx.py      ->  tests/golden/sfx_kink_real_axis.json
 
 `kink(wavenumber, ws, ks, ws_imag, ks_imag, freq)` of
 Slab/Non uniform flow/COMPLEX ANALYSIS/flow_multiprocessor_complex_coronal.py (SF-X:737; the only worker its driver
@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ref_harness as H  # noqa: E402
 
 H.FILES["SF-X"] = "Slab/Non uniform flow/COMPLEX ANALYSIS/flow_multiprocessor_complex_coronal.py"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trace_SFX_kink_real.json")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sfx_kink_real_axis.json")
 LISTS = ["P_diff_check_kink", "all_ws_kink", "all_ws_kink_imag", "sign_check_kink", "all_ks_kink", "all_ks_kink_imag",
          "test_p_diff_kink"]
 
