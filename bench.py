@@ -251,7 +251,7 @@ def main():
         roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
         buf = None
         if world > 1:                                  # the one exchange of the path: a single all-gather
-            buf = D.gather_fixed(D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP), world)
+            buf = D.gather_fixed(D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP, ctx=ctx), world)
         return roots, nbr, buf, st
 
     for _ in range(a.warmup):
@@ -293,7 +293,8 @@ def main():
     n_acc = int((roots["flag"] == 1).sum())
     # grid points one step really evaluates: all of them, or (default) those outside the continuum bands
     n_eval_local = int((st != 3).sum()) if skip else nk_local * NW
-    counts = torch.tensor([float(nbr), float(n_acc), float(n_eval_local)], dtype=torch.float64, device=cdev)
+    counts = torch.tensor([float(nbr), float(n_acc), float(n_eval_local), float(nbr * refine_plan(nbr)[2])],
+                          dtype=torch.float64, device=cdev)
     grid_ms_t = torch.tensor([float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -301,7 +302,7 @@ def main():
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
         dist.all_reduce(grid_ms_t, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    brackets_total, roots_total, grid_points = (int(x) for x in counts.tolist())
+    brackets_total, roots_total, grid_points, refine_evals = (int(x) for x in counts.tolist())
     grid_ms = float(grid_ms_t.item())                # slowest rank's average launch of the dominant kernel
 
     merged = None
@@ -316,8 +317,8 @@ def main():
     if rank == 0:
         if a.dump_roots and merged is not None:
             np.save(a.dump_roots, merged)
-        sections, rounds, ev_per_bracket = refine_plan(brackets_total // world)
-        evals_per_step = grid_points + brackets_total * ev_per_bracket
+        sections, rounds, ev_per_bracket = refine_plan(nbr)          # rank 0's tile (the ranks' counts may differ)
+        evals_per_step = grid_points + refine_evals
         value = evals_per_step * a.steps / dt
         launch_evals = n_eval_local                      # points one launch of the dominant kernel evaluates (rank 0)
         achieved = launch_evals * BYTES_PER_EVAL / (grid_ms * 1e-3) / 1e9
@@ -438,7 +439,7 @@ def main_config4(a):
                 roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
                 nre = 0
             nacc = int((roots["flag"] == 1).sum())
-            buf = D.pack_fixed(roots, nbr, m, rows_t, 1 << 13) if world > 1 else None
+            buf = D.pack_fixed(roots, nbr, m, rows_t, 1 << 13, ctx=prob.ctx) if world > 1 else None
             stream.synchronize()
         return nbr, nacc, nre, buf
 

@@ -160,6 +160,7 @@ def _sig(lib):
     lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
     lib.es_shoot_find_roots_mixed.argtypes = [vp, vp, vp, i, vp, i, i, i, d, vp, vp, C.POINTER(RootTable), C.POINTER(i),
                                               C.POINTER(i)]
+    lib.es_root_table_pack.argtypes = [vp, C.POINTER(RootTable), i, d, vp, i, vp]
     lib.es_worker_run.argtypes = [vp, vp, C.POINTER(WorkerSpec), vp, i, vp, i, vp, vp, i, vp]
     # (4) closed-form uniform cylinder; (5) eigenfunctions
     lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]

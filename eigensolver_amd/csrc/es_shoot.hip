@@ -340,9 +340,12 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
 // D(lo)" and the first set bit picks the sub-interval that keeps the sign change next to lo (the one a scan from lo
 // would find, as the reference's left-to-right 3-point refinement does).  n_rounds = ceil(n_bisect ln2 / ln(LANES+1))
 // rounds shrink the bracket at least as much as n_bisect bisections would; uniform trip count, no divergence.
-// LANES = 16 (17-section: 4 rounds for n_bisect = 16 instead of the 6 of 9-section) while the launch stays below
-// a few waves per SIMD -- the kernel is bound by the sequential marches of one point per lane, not by throughput --
-// LANES = 8 for very many brackets (fewer evaluations in total); refine_sections() is the rule, mirrored by the port.
+// The kernel is bound by the number of SEQUENTIAL marches of one point per lane, not by throughput, as long as the
+// launch stays below a few waves per SIMD: LANES = 16 (17-section, 4 rounds for n_bisect = 16) up to 32768 brackets,
+// LANES = 8 (9-section, 6 rounds; fewest evaluations in total) beyond; refine_sections() is the rule, mirrored by the port.
+// (A 65-section rule for small bracket counts -- one wave per bracket, 3 rounds -- was tried for the k-tiles of a
+// multi-GPU run and dropped: the rule must not depend on how a grid is tiled, or the merged root table of N ranks is
+// no longer the N = 1 table bit for bit.  The threshold below is far above any tile of the bench.)
 __host__ __device__ inline int refine_sections(long n_brackets) { return n_brackets <= 32768 ? 17 : 9; }
 
 template <int FAM, int LANES>
@@ -366,8 +369,9 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
     const double x = lo + (hi - lo) * frac;
     shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     const bool diff = (D * flo < 0.0);                 // NaN products compare false, as in the reference
-    const unsigned bits = (unsigned)((__ballot(diff) >> (LANES * g)) & ((1ull << LANES) - 1ull));
-    const int first = bits ? (__ffs((int)bits) - 1) : LANES;     // first point whose sign differs from D(lo)
+    const unsigned long long bal = __ballot(diff);
+    const unsigned long long bits = (LANES == 64) ? bal : ((bal >> (LANES * g)) & ((1ull << (LANES & 63)) - 1ull));
+    const int first = bits ? (__ffsll((long long)bits) - 1) : LANES;     // first point whose sign differs from D(lo)
     const int src_hi = g * LANES + (first < LANES ? first : LANES - 1);
     const int src_lo = g * LANES + (first > 0 ? first - 1 : 0);
     const double x_hi = __shfl(x, src_hi), d_hi_new = __shfl(D, src_hi);
@@ -1113,7 +1117,22 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
     const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
     // register caps: 128 VGPRs (4 waves per SIMD) for the untwisted family, 168 (3 waves) for the twisted one
     if constexpr (FAM == FAM_CYL0) {
-      if (bands)
+      int v0 = 0;
+      if (const char* ev = getenv("ES_F32_VARIANT")) v0 = atoi(ev);             // tuning aid
+      if (bands && v0 == 1)
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 3>), dim3(grid), dim3(T), 0, ctx->stream,
+                           prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      else if (bands && v0 == 2)
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 2>), dim3(grid), dim3(T), 0, ctx->stream,
+                           prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      else if (bands && v0 == 3) {
+        int T8 = ((nw + 7) / 8 + 63) / 64 * 64;
+        if (T8 < 64) T8 = 64;
+        if (T8 > 256) T8 = 256;
+        const long t8 = (long)nk * ((nw + T8 * 8 - 1) / (T8 * 8));
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, 8, 256, false, 2>), dim3((int)(t8 < (1L << 22) ? t8 : (1L << 22))),
+                           dim3(T8), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+      } else if (bands)
         hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 4>), dim3(grid), dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       else
@@ -1256,4 +1275,43 @@ extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob
     return ES_ERR_SCREENING;
   }
   return total > table->capacity ? ES_ERR_CAPACITY : ES_SUCCESS;
+}
+
+
+// ---- exchange record packing (multi-GPU root-table gather) ---------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void pack_records_kernel(es_root_table tab, int count, double m,
+                                                           const int64_t* __restrict__ rows_global, int cap,
+                                                           double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // row of the send buffer: 0 = header, 1.. = records
+  if (i > cap) return;
+  double* o = out + (size_t)i * 6;
+  if (i == 0) {
+    o[0] = (double)count; o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
+    return;
+  }
+  const int r = i - 1;
+  const int n = count < cap ? count : cap;
+  if (r < n) {
+    const int row = tab.d_row[r];
+    o[0] = tab.d_k[r]; o[1] = tab.d_w[r]; o[2] = m; o[3] = tab.d_resid[r]; o[4] = (double)tab.d_flag[r];
+    o[5] = rows_global ? (double)rows_global[row] : (double)row;
+  } else {
+    o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
+  }
+}
+}  // namespace
+
+extern "C" int es_root_table_pack(es_context* ctx, const es_root_table* table, int count, double m,
+                                  const int64_t* d_rows_global, int cap, double* d_out) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, table && d_out && count >= 0 && cap >= 0, "pack arguments");
+  ES_REQUIRE(ctx, cap == 0 || count == 0 || (table->d_k && table->d_w && table->d_resid && table->d_row && table->d_flag),
+             "null root table arrays");
+  ES_REQUIRE(ctx, (count < cap ? count : cap) <= table->capacity, "count exceeds the table");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(pack_records_kernel, dim3((cap + 1 + 255) / 256), dim3(256), 0, ctx->stream, *table, count, m,
+                     d_rows_global, cap, d_out);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
 }

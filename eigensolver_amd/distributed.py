@@ -68,10 +68,23 @@ def gather_root_tables(roots, m, world=None, group=None):
 N_FIELDS = 6
 
 
-def pack_fixed(roots, count, m, rows_global, cap):
-    """(cap + 1, 6) send buffer on the device of `roots`; rows_global[i] = global k-row of local row i (tensor)."""
+def pack_fixed(roots, count, m, rows_global, cap, ctx=None):
+    """(cap + 1, 6) send buffer on the device of `roots`; rows_global[i] = global k-row of local row i (int64 tensor).
+    With a library context (GPU tensors) the buffer is filled by ONE kernel (es_root_table_pack); the torch path is
+    the same layout for CPU tensors (gloo tests)."""
     import torch
     dev = roots["w"].device
+    if ctx is not None and roots["w"].is_cuda:
+        import ctypes as C
+        from . import _lib
+        send = torch.empty((cap + 1, N_FIELDS), dtype=torch.float64, device=dev)
+        rt = _lib.RootTable(roots["k"].data_ptr(), roots["w"].data_ptr(), roots["w_lo"].data_ptr(),
+                            roots["w_hi"].data_ptr(), roots["resid"].data_ptr(), roots["row"].data_ptr(),
+                            roots["flag"].data_ptr(), int(roots["w"].numel()))
+        rg = rows_global.to(torch.int64).contiguous()
+        _lib.check(ctx.handle, ctx.lib.es_root_table_pack(ctx.handle, C.byref(rt), int(count), float(m),
+                                                          C.c_void_p(rg.data_ptr()), int(cap), _lib.ptr(send)))
+        return send
     send = torch.zeros((cap + 1, N_FIELDS), dtype=torch.float64, device=dev)
     n = min(int(count), cap, roots["w"].numel())
     send[0, 0] = float(count)

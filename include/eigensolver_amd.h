@@ -213,6 +213,14 @@ int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const dou
                               const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
                               double* d_D, uint8_t* d_status, es_root_table* table, int* h_count, int* h_stats);
 
+/* Send buffer of the multi-GPU exchange (one all-gather of fixed-capacity buffers per step):
+ * d_out is (cap + 1) x 6 doubles, row 0 = (count, 0, ...), rows 1 .. min(count, cap) = (k, omega, m, resid, flag,
+ * global row) of the first records of `table`, the rest zero.  d_rows_global[local row] maps the rows of a k-tile to
+ * the rows of the whole grid (NULL: identity).  Replaces the reference's positional pairing of two Queues
+ * (Density_cylinder.py:1155-1168).  Asynchronous on the context's stream. */
+int es_root_table_pack(es_context* ctx, const es_root_table* table, int count, double m,
+                       const int64_t* d_rows_global, int cap, double* d_out);
+
 /* ========================================================================================================
  * (3) The reference worker itself: kink(wavenumber, kink_ws, kink_ks, freq) / sausage(...) for a batch of
  *     (wavenumber, freq[]) tasks -- main loop over freq, acceptance test, sign-change detection against the

@@ -559,7 +559,7 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
   long n = count < capacity ? count : capacity;
   int rounds = 0;
   const int polish = 2;
-  /* (LANES+1)-section as the HIP refine_kernel: 17 sections (16 lanes per bracket) up to 32768 brackets, 9 beyond */
+  /* (LANES+1)-section as the HIP refine_kernel (refine_sections): 17 up to 32768 brackets, 9 beyond */
   const int sections = (n <= 32768) ? 17 : 9;
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
 #ifdef _OPENMP
@@ -574,7 +574,7 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
     /* multi-section rounds, as the HIP refine_kernel: points lo + (hi-lo)*(j+1)/sections, first sign change from the left */
     const int L = sections - 1;
     for (int it = 0; it < rounds; ++it) {
-      double x[16], dv[16];
+      double x[64], dv[64];
       int first = L;
       for (int j = 0; j < L; ++j) {
         x[j] = lo + (hi - lo) * ((double)(j + 1) / (double)sections);
