@@ -419,83 +419,104 @@ constexpr double F32_TAU_D = 5e-2;
 constexpr double F32_TAU_POLE = 5e-2;
 constexpr uint8_t F32_UNSURE = 0x80;
 
-struct CoefF { float a11, a12, a21, a22; };
-struct CoefPreF { float n11, n12, n21, n22, den; };
+// All fp32 arithmetic of the march is written on PAIRS of points (clang ext-vector float2 -> v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32: two points per instruction); node entries are wave-uniform scalars broadcast to both
+// halves by the packed instructions' operand selects.
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// What the screening pass remembers per point about the watched terms (t1 = Om^2 - omega_A^2, t2 = Om^2 - omega_c^2 and,
-// twisted family, C3): running minimum and maximum of t1 and t2 over the nodes (2 instructions per term and node) and,
-// for C3, the sign bits of C3 D as in the fp64 kernel plus the minimum of |C3| - tau |D (rho t1 + r d/dr[..])| (how close C3
-// came to zero relative to its leading part).  With S = tau (omega^2 + omega_A^2(boundary)) a term is
-//   certainly of one sign   if min > S or max < -S,
-//   certainly crossing zero if min < -S and max > S   (=> ES_PT_CONTINUUM whatever happens next to the zero),
-//   anything else sends the point to fp64.
+__device__ __forceinline__ v2f v2(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vabs(v2f a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ v2f vmin(v2f a, v2f b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2f vmax(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2f vrcp(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+
+struct CoefF { v2f a11, a12, a21, a22; };
+struct CoefPreF { v2f n11, n12, n21, n22, den; };
+
+// What the screening pass remembers per point about the watched terms of the coefficient set:
+//   band families (status known exactly from W = omega/k): the minimum over the nodes of |t1 t2| = |den| / (rho S) --
+//     how close Om^2 came to omega_A^2 or omega_c^2 (1 instruction per point and node);
+//   tracked families: running minimum and maximum of t1 and t2 and, twisted family, the sign bits of C3 D as in the
+//     fp64 kernel plus the minimum of |C3| - tau |D (rho t1 + r d/dr[..])| (how close C3 came to zero relative to its
+//     leading part).
+// With S = tau (omega^2 + omega_A^2(boundary)) a tracked term is certainly of one sign if min > S or max < -S, certainly
+// crossing zero if min < -S and max > S (=> ES_PT_CONTINUUM whatever happens next to the zero); anything else sends the
+// point to fp64.
+template <bool TRACK>
 struct ScreenF {
-  float lo1 = 3.0e38f, hi1 = -3.0e38f, lo2 = 3.0e38f, hi2 = -3.0e38f;
-  float c3m = 3.0e38f;
-  int or3 = 0, and3 = -1;
+  v2f mn = {3.0e38f, 3.0e38f};                          // !TRACK: min |t1 t2|
+  v2f lo1 = {3.0e38f, 3.0e38f}, hi1 = {-3.0e38f, -3.0e38f}, lo2 = {3.0e38f, 3.0e38f}, hi2 = {-3.0e38f, -3.0e38f};
+  v2f c3m = {3.0e38f, 3.0e38f};
+  int or3[2] = {0, 0}, and3[2] = {-1, -1};
 };
 
-template <int FAM>
-__device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, float w, CoefPreF& C, ScreenF& sc) {
-  const float Om = w - e[0];
-  const float Om2 = Om * Om;
-  const float t1 = Om2 - e[1];
-  const float t2 = Om2 - e[2];
-  sc.lo1 = fminf(sc.lo1, t1); sc.hi1 = fmaxf(sc.hi1, t1);
-  sc.lo2 = fminf(sc.lo2, t2); sc.hi2 = fmaxf(sc.hi2, t2);
-  if (FAM == FAM_CYL0) {
-    C.n11 = 0.0f;
-    C.n12 = e[3] * t1;
-    C.n21 = fmaf(e[5], t2, e[6]);
-    C.n22 = e[4];
-    C.den = t1 * t2;
+template <int FAM, bool TRACK>
+__device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, v2f w, CoefPreF& C, ScreenF<TRACK>& sc) {
+  const v2f Om = w - v2(e[0]);
+  const v2f Om2 = Om * Om;
+  const v2f t1 = Om2 - v2(e[1]);
+  const v2f t2 = Om2 - v2(e[2]);
+  const v2f t12 = t1 * t2;
+  if (TRACK) {
+    sc.lo1 = vmin(sc.lo1, t1); sc.hi1 = vmax(sc.hi1, t1);
+    sc.lo2 = vmin(sc.lo2, t2); sc.hi2 = vmax(sc.hi2, t2);
   } else {
-    const float D = e[3] * t1 * t2;
-    const float Q = fmaf(Om, e[7], fmaf(Om2, e[6], -(t1 * e[5])));
-    const float T = fmaf(e[9], Om, e[8]);
-    const float OmP = (c1_power == 2) ? Om2 : Om;
-    const float t2T = t2 * T;
-    const float C1 = fmaf(Q, OmP, -(e[10] * t2T));
-    const float C2 = fmaf(Om2, Om2, -(e[11] * t2));
-    const float c3a = D * fmaf(e[4], t1, e[12]);
-    const float C3 = c3a + fmaf(Q, Q, -(e[13] * t2T * T));
-    const int b = __float_as_int(C3 * D);               // sign of F = r D / C3, third watched term of the fp64 kernel
-    sc.or3 |= b;
-    sc.and3 &= b;
-    sc.c3m = fminf(sc.c3m, fmaf(-F32_TAU_NODE, fabsf(c3a), fabsf(C3)));
+    sc.mn = vmin(sc.mn, vabs(t12));
+  }
+  if (FAM == FAM_CYL0) {
+    C.n11 = v2(0.0f);
+    C.n12 = v2(e[3]) * t1;
+    C.n21 = vfma(v2(e[5]), t2, v2(e[6]));
+    C.n22 = v2(e[4]);
+    C.den = t12;
+  } else {
+    const v2f D = v2(e[3]) * t12;
+    const v2f Q = vfma(Om, v2(e[7]), vfma(Om2, v2(e[6]), -(t1 * v2(e[5]))));
+    const v2f T = vfma(v2(e[9]), Om, v2(e[8]));
+    const v2f OmP = (c1_power == 2) ? Om2 : Om;
+    const v2f t2T = t2 * T;
+    const v2f C1 = vfma(Q, OmP, -(v2(e[10]) * t2T));
+    const v2f C2 = vfma(Om2, Om2, -(v2(e[11]) * t2));
+    const v2f c3a = D * vfma(v2(e[4]), t1, v2(e[12]));
+    const v2f C3 = c3a + vfma(Q, Q, -(v2(e[13]) * t2T * T));
+    const v2f s3 = C3 * D;                              // sign of F = r D / C3, third watched term of the fp64 kernel
+    sc.or3[0] |= __float_as_int(s3.x); sc.and3[0] &= __float_as_int(s3.x);
+    sc.or3[1] |= __float_as_int(s3.y); sc.and3[1] &= __float_as_int(s3.y);
+    sc.c3m = vmin(sc.c3m, vfma(v2(-F32_TAU_NODE), vabs(c3a), vabs(C3)));
     C.n11 = -C1;
     C.n22 = C1;
-    C.n12 = C3 * e[15];
-    C.n21 = -(e[14] * C2);
+    C.n12 = C3 * v2(e[15]);
+    C.n21 = -(v2(e[14]) * C2);
     C.den = D;
   }
 }
 
 template <int FAM>
-__device__ __forceinline__ void coef_finish_f32(const CoefPreF& C, float inv, CoefF& A) {
+__device__ __forceinline__ void coef_finish_f32(const CoefPreF& C, v2f inv, CoefF& A) {
   if (FAM == FAM_CYL0) {
-    A.a11 = 0.0f; A.a22 = 0.0f; A.a12 = C.n12; A.a21 = fmaf(C.n21, inv, C.n22);
+    A.a11 = v2(0.0f); A.a22 = v2(0.0f); A.a12 = C.n12; A.a21 = vfma(C.n21, inv, C.n22);
   } else {
     A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
   }
 }
 
 template <int FAM>
-__device__ __forceinline__ void rk4_step_adjoint_f32(float& p, float& q, const CoefF& B0, const CoefF& Bm, const CoefF& B1,
+__device__ __forceinline__ void rk4_step_adjoint_f32(v2f& p, v2f& q, const CoefF& B0, const CoefF& Bm, const CoefF& B1,
                                                      float h, float h2, float h6, float h3) {
 #define ES_RHS_TF(A, pp, qq, kp, kq)                                                            \
-  if (FAM == FAM_CYLT) { kp = fmaf(A.a11, pp, A.a21 * qq); kq = fmaf(A.a22, qq, A.a12 * pp); } \
+  if (FAM == FAM_CYLT) { kp = vfma(A.a11, pp, A.a21 * qq); kq = vfma(A.a22, qq, A.a12 * pp); } \
   else                 { kp = A.a21 * qq;                  kq = A.a12 * pp; }
-  float k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
+  v2f k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
   ES_RHS_TF(B0, p, q, k1p, k1q);
-  tp = fmaf(h2, k1p, p); tq = fmaf(h2, k1q, q);
+  tp = vfma(v2(h2), k1p, p); tq = vfma(v2(h2), k1q, q);
   ES_RHS_TF(Bm, tp, tq, k2p, k2q);
-  tp = fmaf(h2, k2p, p); tq = fmaf(h2, k2q, q);
+  tp = vfma(v2(h2), k2p, p); tq = vfma(v2(h2), k2q, q);
   ES_RHS_TF(Bm, tp, tq, k3p, k3q);
-  tp = fmaf(h, k3p, p); tq = fmaf(h, k3q, q);
+  tp = vfma(v2(h), k3p, p); tq = vfma(v2(h), k3q, q);
   ES_RHS_TF(B1, tp, tq, k4p, k4q);
-  p = fmaf(h6, k1p + k4p, fmaf(h3, k2p + k3p, p));
-  q = fmaf(h6, k1q + k4q, fmaf(h3, k2q + k3q, q));
+  p = vfma(v2(h6), k1p + k4p, vfma(v2(h3), k2p + k3p, p));
+  q = vfma(v2(h6), k1q + k4q, vfma(v2(h3), k2q + k3q, q));
 #undef ES_RHS_TF
 }
 
@@ -508,6 +529,8 @@ template <int FAM, int PTS, int MAXT, bool TRACK, int WPE>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, const double* __restrict__ wv, int nw,
                            int w_mode, double* __restrict__ Dout, uint8_t* __restrict__ stout) {
+  static_assert(PTS % 2 == 0, "points are processed in pairs");
+  constexpr int NP = PTS / 2;
   constexpr int NE = FamTraits<FAM>::NE;
   constexpr int LSTRIDE = 2 * CH + 1;
   __shared__ float lds[NE * LSTRIDE];
@@ -521,23 +544,25 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
     const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
-    float wf[PTS], zp[PTS], zq[PTS];
-    int zexp[PTS];                                     // accumulated power-of-two scaling of (zp, zq)
-    CoefF B0[PTS], B1[PTS];
-    ScreenF scr[PTS];
+    v2f wf[NP], zp[NP], zq[NP];
+    int zexp[PTS];                                     // accumulated power-of-two scaling of (zp, zq), per point
+    CoefF B0[NP], B1[NP];
+    ScreenF<TRACK> scr[NP];
     bool lane_live = false;
 #pragma unroll
     for (int p = 0; p < PTS; ++p) {
       const int iw = w0 + p * T + (int)threadIdx.x;
       const double w = (iw < nw) ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
-      wf[p] = (float)w;
+      if (p & 1) wf[p >> 1].y = (float)w; else wf[p >> 1].x = (float)w;
       // m_e > 0 (evanescent exterior) and, for the band families, not inside a continuum band: worth a march
       const double k2 = k * k, w2 = w * w;
       const double m_e = ((k2 * P.vAe2 - w2) * (k2 * P.ce2 - w2)) / (P.Se * (k2 * P.cTe2 - w2));
       const bool dead = !TRACK && band_crossed(P, k, w);
       lane_live = lane_live || (iw < nw && m_e > 0.0 && !dead);
-      zp[p] = 0.0f; zq[p] = 0.0f; zexp[p] = 0;
+      zexp[p] = 0;
     }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { zp[p] = v2(0.0f); zq[p] = v2(0.0f); }
     const bool wave_live = __any(lane_live);
     const bool wg_live = __syncthreads_or(wave_live ? 1 : 0) != 0;
     const int nchunks = wg_live ? (nsteps + CH - 1) / CH : 0;
@@ -559,11 +584,11 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
 #pragma unroll
         for (int f = 0; f < NE; ++f) eL[f] = lds[f * LSTRIDE + 2 * nst];
 #pragma unroll
-        for (int p = 0; p < PTS; ++p) {
+        for (int p = 0; p < NP; ++p) {
           CoefPreF C;
-          coef_pre_f32<FAM>(eL, P.c1_power, wf[p], C, scr[p]);
-          coef_finish_f32<FAM>(C, 1.0f / C.den, B0[p]);
-          if (P.axis_bc == ES_AXIS_SAUSAGE) { zp[p] = B0[p].a11; zq[p] = B0[p].a12; } else { zp[p] = 1.0f; zq[p] = 0.0f; }
+          coef_pre_f32<FAM, TRACK>(eL, P.c1_power, wf[p], C, scr[p]);
+          coef_finish_f32<FAM>(C, v2(1.0f) / C.den, B0[p]);
+          if (P.axis_bc == ES_AXIS_SAUSAGE) { zp[p] = B0[p].a11; zq[p] = B0[p].a12; } else { zp[p] = v2(1.0f); zq[p] = v2(0.0f); }
         }
       }
 #define ES_F32_STEP(J, BIN, BOUT)                                                                   \
@@ -573,11 +598,11 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
           em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                                   \
           e1[f] = lds[f * LSTRIDE + 2 * (J)];                                                       \
         }                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                           \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                            \
           CoefPreF Cm, C1;                                                                          \
-          coef_pre_f32<FAM>(em, P.c1_power, wf[p], Cm, scr[p]);                                     \
-          coef_pre_f32<FAM>(e1, P.c1_power, wf[p], C1, scr[p]);                                     \
-          const float inv = __builtin_amdgcn_rcpf(Cm.den * C1.den);                                 \
+          coef_pre_f32<FAM, TRACK>(em, P.c1_power, wf[p], Cm, scr[p]);                              \
+          coef_pre_f32<FAM, TRACK>(e1, P.c1_power, wf[p], C1, scr[p]);                              \
+          const v2f inv = vrcp(Cm.den * C1.den);                                                    \
           CoefF Bm;                                                                                 \
           coef_finish_f32<FAM>(Cm, C1.den * inv, Bm);                                               \
           coef_finish_f32<FAM>(C1, Cm.den * inv, BOUT[p]);                                          \
@@ -590,22 +615,25 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       if (nst & 1) {
         ES_F32_STEP(j, B0, B1)
 #pragma unroll
-        for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+        for (int p = 0; p < NP; ++p) B0[p] = B1[p];
         --j;
       }
       for (; j >= 1; j -= 2) {
         ES_F32_STEP(j, B0, B1)
         ES_F32_STEP(j - 1, B1, B0)
-        if (((j - 1) & 15) == 0) {                     // renormalise every 16 steps
+        if (((j - 1) & 31) == 0) {                     // renormalise every 32 steps
 #pragma unroll
           for (int p = 0; p < PTS; ++p) {
-            const float mag = fmaxf(fabsf(zp[p]), fabsf(zq[p]));
+            float a = (p & 1) ? zp[p >> 1].y : zp[p >> 1].x;
+            float b = (p & 1) ? zq[p >> 1].y : zq[p >> 1].x;
+            const float mag = fmaxf(fabsf(a), fabsf(b));
             if (mag > 1.0995116e12f || (mag < 9.094947e-13f && mag > 0.0f)) {       // outside [2^-40, 2^40]
               int ex;
               (void)frexpf(mag, &ex);
-              zp[p] = ldexpf(zp[p], -ex);
-              zq[p] = ldexpf(zq[p], -ex);
+              a = ldexpf(a, -ex);
+              b = ldexpf(b, -ex);
               zexp[p] += ex;
+              if (p & 1) { zp[p >> 1].y = a; zq[p >> 1].y = b; } else { zp[p >> 1].x = a; zq[p >> 1].x = b; }
             }
           }
         }
@@ -621,27 +649,37 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       if (iw >= nw) continue;
       const double w = pick_w(wv, w_mode, k, row, nw, iw);
       const ExteriorLite X = exterior_lite(P, k, w, w);
+      const bool hi_half = (p & 1);
+      const ScreenF<TRACK>& sc = scr[p >> 1];
+      const float zpp = hi_half ? zp[p >> 1].y : zp[p >> 1].x;
+      const float zqq = hi_half ? zq[p >> 1].y : zq[p >> 1].x;
       // r = (r1, r2) * 2^zexp: the common factor multiplies the homogeneous part of the axis condition; its target
       // (bc_const * xi_e, non-zero only for the twisted kink condition) is divided by it instead
       ShootDev Pl = P;
       Pl.bc_const = P.bc_const * ldexp(1.0, -zexp[p]);
-      const Mismatch M = boundary_algebra<FAM>(Pl, s, w, X, (double)zp[p], (double)zq[p], ef);
+      const Mismatch M = boundary_algebra<FAM>(Pl, s, w, X, (double)zpp, (double)zqq, ef);
       // watched terms: certain sign / certain crossing / unsure (see ScreenF)
       const float S = F32_TAU_NODE * (float)(w * w + ef[1]);
-      const ScreenF& sc = scr[p];
-      const bool cross12 = (sc.lo1 < -S && sc.hi1 > S) || (sc.lo2 < -S && sc.hi2 > S);
-      const bool sure12 = (sc.lo1 > S || sc.hi1 < -S) && (sc.lo2 > S || sc.hi2 < -S);
       bool crossed, node_unsure;
       if (!TRACK) {                                     // band families: the status is exact (fp64 test on W = omega/k)
         crossed = band_crossed(P, k, w);
-        node_unsure = !crossed && !sure12;              // an evaluated point with a coefficient close to a singular point
-      } else if (cross12) {
-        crossed = true; node_unsure = false;
-      } else if (sure12 && (FAM != FAM_CYLT || sc.c3m >= 0.0f)) {
-        crossed = (FAM == FAM_CYLT) && ((sc.or3 & ~sc.and3) < 0);
-        node_unsure = false;
+        const float mnp = hi_half ? sc.mn.y : sc.mn.x;
+        node_unsure = !crossed && !(mnp > S * S);       // an evaluated point with a coefficient close to a singular point
       } else {
-        crossed = false; node_unsure = true;
+        const float lo1 = hi_half ? sc.lo1.y : sc.lo1.x, hi1 = hi_half ? sc.hi1.y : sc.hi1.x;
+        const float lo2 = hi_half ? sc.lo2.y : sc.lo2.x, hi2 = hi_half ? sc.hi2.y : sc.hi2.x;
+        const float c3m = hi_half ? sc.c3m.y : sc.c3m.x;
+        const int or3 = sc.or3[p & 1], and3 = sc.and3[p & 1];
+        const bool cross12 = (lo1 < -S && hi1 > S) || (lo2 < -S && hi2 > S);
+        const bool sure12 = (lo1 > S || hi1 < -S) && (lo2 > S || hi2 < -S);
+        if (cross12) {
+          crossed = true; node_unsure = false;
+        } else if (sure12 && (FAM != FAM_CYLT || c3m >= 0.0f)) {
+          crossed = (FAM == FAM_CYLT) && ((or3 & ~and3) < 0);
+          node_unsure = false;
+        } else {
+          crossed = false; node_unsure = true;
+        }
       }
       double D, rel; uint8_t st;
       finish_point(P, M, X, crossed, D, rel, st);
@@ -1139,8 +1177,8 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
         hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 4>), dim3(grid), dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
     } else {
-      // measured on configs[4] (1024^2, N = 2000): 4 points per lane at 2 waves per SIMD (no spills) 5.7 ms; the same
-      // capped at 168 registers (3 waves) spills inside the loop, 16.0 ms; 2 points per lane at 4 waves 6.1 ms; fp64 9.4 ms
+      // measured on configs[4] (1024^2, N = 2000), packed fp32: 4 points per lane at 2 waves per SIMD (no spills) 4.5 ms;
+      // the same capped at 168 registers (3 waves, spills) 5.6 ms; 2 points per lane at 4 waves 4.7 ms; fp64 9.4 ms
       int variant = 1;
       if (const char* ev = getenv("ES_F32_VARIANT")) variant = atoi(ev);        // tuning aid
       if (variant == 1) {
