@@ -13,6 +13,10 @@ detection (wave shuffle + ballot), 9-section + secant refinement, ordered root c
 The kernels run on torch's current stream of the device (the stream the es_context is created with), so the
 torch.cuda.Event pairs around the grid launch time exactly that kernel.
 
+Consecutive steps are software-pipelined over --streams S (default 2) library contexts = HIP streams, one host thread
+each: grid launches stay serialised (each has the whole chip), the latency-bound bracket refinement of step i (about
+one wave per SIMD) overlaps the grid launch of step i + 1; collectives are issued by the main thread in step order.
+
 Multi-GPU (default --mode strong): the 4096 k-rows of the ONE grid are tiled across the ranks (strided: rank r owns
 rows r, r + N, ... -- the reference's per-k process fan-out, Density_cylinder.py:1142-1153), no data-path collective;
 the only exchange is one RCCL all-gather of the fixed-capacity root tables per step.  --mode weak-m is the (k, m)
@@ -185,6 +189,9 @@ def main():
                          "evaluates every point; the skip mode is then measured after the timed region and reported "
                          "under config.skip_continuum_mode")
     ap.add_argument("--dump-roots", default=None, help="write the merged root table of the last step to this .npy")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="software pipelining of consecutive steps: S library contexts (HIP streams), each driven by its own "
+                         "host thread; the latency-bound refinement of step i overlaps the grid launch of step i + 1")
     ap.add_argument("--no-extra-mode", action="store_true",
                     help="do not measure the other continuum mode after the timed region (profiling runs: keeps the "
                          "per-kernel counters of one mode apart)")
@@ -229,40 +236,98 @@ def main():
     from eigensolver_amd import ShootProblem, _lib
     from eigensolver_amd import distributed as D
     dev = torch.device(f"cuda:{local_rank}")
-    ctx = _lib.Context(local_rank)
     strong = a.mode == "strong"
     m = 1 if strong else rank + 1                  # weak-m: rank r owns azimuthal order m = r + 1
-    prob = ShootProblem(eq, "kink", m=m, ctx=ctx)
     rows_np = D.tile_rows(NK, rank, world, strided=True) if strong else np.arange(NK)
     rows_t = torch.as_tensor(rows_np, device=dev)
     k = torch.as_tensor(k_np[rows_np], dtype=torch.float64, device=dev)
     W = torch.as_tensor(W_np, dtype=torch.float64, device=dev)
     nk_local = int(k.numel())
-    table = prob.alloc_root_table(1 << 18)
+    # one lane = (stream, library context, problem, root table); --streams 1: the current stream, everything inline
+    n_lanes = max(1, a.streams)
+    lanes = []
+    for j in range(n_lanes):
+        stream = torch.cuda.current_stream(dev) if n_lanes == 1 else torch.cuda.Stream(device=dev)
+        cx = _lib.Context(local_rank, stream=stream)
+        pr = ShootProblem(eq, "kink", m=m, ctx=cx)
+        with torch.cuda.stream(stream):
+            tb = pr.alloc_root_table(1 << 18)
+        lanes.append((stream, cx, pr, tb))
+    ctx, prob = lanes[0][1], lanes[0][2]
+    torch.cuda.synchronize()
 
     skip = bool(a.skip_continuum)
+    import threading
+    grid_lock = threading.Lock()
+    grid_tail = [None]                             # event after the most recent grid launch of any lane
+
+    def compute(j, ev=None):
+        """One pass of the hot path over the rank's tile on lane j; returns with the refinement and the send buffer of the
+        exchange enqueued (`done` marks their completion on the lane's stream)."""
+        stream, cx, pr, tb = lanes[j]
+        with torch.cuda.stream(stream):
+            # grid launches of different lanes run one after the other (each has the whole chip, and the events below
+            # time one launch); what overlaps with the NEXT step's grid is this step's bracket search and refinement
+            with grid_lock:
+                if grid_tail[0] is not None:
+                    stream.wait_event(grid_tail[0])
+                if ev is not None:
+                    ev[0].record(stream)
+                D_, st = pr.eval_grid(k, W, skip_continuum=skip)
+                if ev is not None:
+                    ev[1].record(stream)
+                tail = torch.cuda.Event()
+                tail.record(stream)
+                grid_tail[0] = tail
+            roots, nbr = pr.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=tb)
+            send = D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP, ctx=cx) if world > 1 else None
+            done = torch.cuda.Event()
+            done.record(stream)
+        return roots, nbr, send, st, done
+
+    def exchange(send, done):
+        # the one exchange of the path: a single all-gather, issued by the main thread in step order on every rank
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(done)
+        send.record_stream(cur)                        # allocated on the lane's stream, read by the collective on this one
+        return D.gather_fixed(send, world)
 
     def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        D_, st = prob.eval_grid(k, W, skip_continuum=skip)
-        if ev is not None:
-            ev[1].record()
-        roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
-        buf = None
-        if world > 1:                                  # the one exchange of the path: a single all-gather
-            buf = D.gather_fixed(D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP, ctx=ctx), world)
+        roots, nbr, send, st, done = compute(0, ev)
+        buf = exchange(send, done) if world > 1 else None
         return roots, nbr, buf, st
 
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    free_lanes = queue.Queue()
+    for j in range(n_lanes):
+        free_lanes.put(j)
+
+    def pipelined(ev):
+        j = free_lanes.get()
+        try:
+            return compute(j, ev)
+        finally:
+            free_lanes.put(j)
+
     for _ in range(a.warmup):
-        step()
+        for j in range(n_lanes):
+            compute(j)
+        torch.cuda.synchronize()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    pool = ThreadPoolExecutor(max_workers=n_lanes) if n_lanes > 1 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        roots, nbr, buf, st = step(events[i])
+    if pool is None:
+        for i in range(a.steps):
+            roots, nbr, buf, st = step(events[i])
+    else:
+        futs = [pool.submit(pipelined, events[i]) for i in range(a.steps)]
+        for f in futs:
+            roots, nbr, send, st, done = f.result()
+            buf = exchange(send, done) if world > 1 else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -358,6 +423,7 @@ def main():
                                             "every point; the continuum fraction of grid_point_status_fractions is never "
                                             "bracketed"),
                        ("all_points_marched_mode" if skip else "skip_continuum_mode"): other,
+                       "pipelined_streams": n_lanes,
                        "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": "shoot_grid_kernel<FAM_CYL0>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

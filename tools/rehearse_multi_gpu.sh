@@ -6,9 +6,9 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 export ES_BENCH_BACKEND=gloo ES_BENCH_SHARE_GPU=1
-python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --dump-roots $R/gpurun_out/roots_n1.npy > $R/gpurun_out/rehearse_n1.json 2> $R/gpurun_out/rehearse_n1.err || exit 1
+python $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS --dump-roots $R/gpurun_out/roots_n1.npy > $R/gpurun_out/rehearse_n1.json 2> $R/gpurun_out/rehearse_n1.err || exit 1
 for N in ${1:-2 4}; do
-  python $R/bench.py --gpus $N --steps 2 --warmup 1 --no-cpu-baseline --dump-roots $R/gpurun_out/roots_n$N.npy > $R/gpurun_out/rehearse_n$N.json 2> $R/gpurun_out/rehearse_n$N.err || { tail -5 $R/gpurun_out/rehearse_n$N.err; exit 2; }
+  python $R/bench.py --gpus $N --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS --dump-roots $R/gpurun_out/roots_n$N.npy > $R/gpurun_out/rehearse_n$N.json 2> $R/gpurun_out/rehearse_n$N.err || { tail -5 $R/gpurun_out/rehearse_n$N.err; exit 2; }
   python - <<PY || exit 3
 import json, numpy as np
 a = np.load("$R/gpurun_out/roots_n1.npy"); b = np.load("$R/gpurun_out/roots_n$N.npy")
