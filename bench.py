@@ -314,7 +314,9 @@ def main():
     for _ in range(a.warmup):
         for j in range(n_lanes):
             e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            compute(j, e)
+            _, _, send_w, _, done_w = compute(j, e)
+            if world > 1:
+                exchange(send_w, done_w)            # also brings the communicator up before the timed region
             torch.cuda.synchronize()
             unshared.append(e[0].elapsed_time(e[1]))
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
