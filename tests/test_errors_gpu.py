@@ -60,3 +60,46 @@ def test_invalid_arguments_are_rejected(es_ctx):
     Dg, stg = gp.eval_grid([1.0, 2.0], [3.0, 3.5])
     assert torch.isfinite(Dg).all()
     gp.close()
+
+
+def test_round2_entry_points_reject_bad_input_and_handle_edges(es_ctx):
+    """es_shoot_eval_grid_ex, es_shoot_find_roots_mixed, es_root_table_pack: unknown flags, null pointers, a root
+    table that is too small (count still returned, first records valid), empty and one-column grids."""
+    import torch
+    from eigensolver_amd import _lib, ShootProblem, equilibrium as q
+    lib = es_ctx.lib
+    eq = q.CylinderFlow(U_i0=0.6, width=1.0)
+    gp = ShootProblem(eq, "kink", ctx=es_ctx)
+    k = torch.linspace(0.5, 3.5, 6, dtype=torch.float64, device="cuda")
+    W = torch.linspace(0.95, 4.9, 97, dtype=torch.float64, device="cuda")
+    D = torch.empty((6, 97), dtype=torch.float64, device="cuda")
+    st = torch.empty((6, 97), dtype=torch.uint8, device="cuda")
+    args = (es_ctx.handle, gp.handle, _lib.ptr(k), 6, _lib.ptr(W), 97, 1)
+    assert lib.es_shoot_eval_grid_ex(*args, 8, _lib.ptr(D), None, _lib.ptr(st)) == 1          # unknown flag bit
+    assert b"flags" in lib.es_last_error(es_ctx.handle)
+    assert lib.es_shoot_eval_grid_ex(*args, 1, None, None, _lib.ptr(st)) == 1                  # null output
+    assert lib.es_shoot_eval_grid_ex(*args, 1, _lib.ptr(D), None, _lib.ptr(st)) == 0
+    # skip flag on grids narrower than a wave and with a single column / row
+    for nk, nw in ((1, 1), (2, 5), (1, 64)):
+        Ds, ss = gp.eval_grid(k[:nk], W[:nw], skip_continuum=True)
+        D0, s0 = gp.eval_grid(k[:nk], W[:nw])
+        assert torch.equal(ss, s0)
+        keep = s0 != 3
+        assert torch.equal(Ds[keep].nan_to_num(7.0), D0[keep].nan_to_num(7.0))
+    # mixed search: capacity below the number of brackets
+    full, cnt, _, _, stats = gp.find_roots_mixed(k, W, n_bisect=16)
+    assert cnt > 4 and stats[2] == 0
+    small, cnt2, _, _, _ = gp.find_roots_mixed(k, W, n_bisect=16, capacity=3)
+    assert cnt2 == cnt and small["w"].numel() == 3 and torch.equal(small["w"], full["w"][:3])
+    # null table
+    n = C.c_int(0)
+    assert lib.es_shoot_find_roots_mixed(es_ctx.handle, gp.handle, _lib.ptr(k), 6, _lib.ptr(W), 97, 1, 16, 1e-3,
+                                         _lib.ptr(D), _lib.ptr(st), None, C.byref(n), None) == 1
+    # pack: count larger than the table it points to
+    t, rt = gp.alloc_root_table(4)
+    out = torch.empty((9, 6), dtype=torch.float64, device="cuda")
+    assert lib.es_root_table_pack(es_ctx.handle, C.byref(rt), 6, 1.0, None, 8, _lib.ptr(out)) == 1
+    assert lib.es_root_table_pack(es_ctx.handle, C.byref(rt), 0, 1.0, None, 8, _lib.ptr(out)) == 0
+    es_ctx.synchronize()
+    assert float(out[0, 0]) == 0.0 and float(out.abs().sum()) == 0.0
+    gp.close()
