@@ -664,7 +664,10 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       if (!TRACK) {                                     // band families: the status is exact (fp64 test on W = omega/k)
         crossed = band_crossed(P, k, w);
         const float mnp = hi_half ? sc.mn.y : sc.mn.x;
-        node_unsure = !crossed && !(mnp > S * S);       // an evaluated point with a coefficient close to a singular point
+        // an evaluated point with a coefficient close to a singular point: |t1 t2| below tau (omega^2 + omega_A^2)^2 at
+        // some node, i.e. ONE of the two factors within tau of zero relative to its size
+        const float sz = (float)(w * w + ef[1]);
+        node_unsure = !crossed && !(mnp > F32_TAU_NODE * sz * sz);
       } else {
         const float lo1 = hi_half ? sc.lo1.y : sc.lo1.x, hi1 = hi_half ? sc.hi1.y : sc.hi1.x;
         const float lo2 = hi_half ? sc.lo2.y : sc.lo2.x, hi2 = hi_half ? sc.hi2.y : sc.hi2.x;
@@ -683,6 +686,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       }
       double D, rel; uint8_t st;
       finish_point(P, M, X, crossed, D, rel, st);
+      if (!TRACK && crossed && X.status == ES_PT_OK) { st = ES_PT_CONTINUUM; D = NAN; }   // not marched: no D to judge
       bool unsure = false;
       if (X.status == ES_PT_OK && crossed) {
         unsure = TRACK && !isfinite(M.d);               // fp64 reports ES_PT_NONFINITE before ES_PT_CONTINUUM: let it decide

@@ -26,6 +26,8 @@ def solver_factories():
         "SFU": ("SF-U", lambda ctx=None: E.SlabUniformFlow(ctx=ctx)),
         "SFG_uniform": ("SF-G", lambda ctx=None: E.SlabNonUniformFlow(U_i0=0.9, width=1e5, ctx=ctx)),
         "SFG_flow": ("SF-G", lambda ctx=None: E.SlabNonUniformFlow(U_i0=0.35, width=1.5, ctx=ctx)),
+        "SFG_flow_neg": ("SF-G", lambda ctx=None: E.SlabNonUniformFlow(U_i0=0.35, width=1.5, ctx=ctx)),
+        "CDC_w095_neg": ("CD-C", lambda ctx=None: E.CylinderNonUniformDensity(width=0.95, ctx=ctx)),
         "SDP_uniform": ("SD-P", lambda ctx=None: E.SlabNonUniformDensity(width=1e5, ctx=ctx)),
         "SDP_w15": ("SD-P", lambda ctx=None: E.SlabNonUniformDensity(width=1.5, ctx=ctx)),
         "SDC_w09": ("SD-C", lambda ctx=None: E.SlabNonUniformDensity(width=0.9, coronal=True, ctx=ctx)),

@@ -226,6 +226,11 @@ ROOTSETS = {
                     ("kink", "sausage")),
     "CRSS": ("CR-SS", [], [0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5], [(0.9, 0.92), (0.94, 0.96), (0.98, 1.0)], 40, ("sausage",)),
     "SFU": ("SF-U", [], [0.3, 0.9, 1.5, 2.1, 2.7, 3.3], ["sfu_log", "sfu_body"], 0, ("kink", "sausage")),
+    # NEGATIVE frequencies: the sorted `speeds` of SF-G (-vA_e first, SF-G:180) and CD-C (-vA_e ... -cT_i0, CD-C:225) make
+    # the reference drivers scan omega < 0 bands too; with a flow they are not the mirror image of the positive ones
+    "SFG_flow_neg": ("SF-G", [("dx=1e5", "dx=1.5"), ("U_i0 = 0.9*vA_i", "U_i0 = 0.35*vA_i")],
+                     [0.5, 1.5, 2.5], [(-2.45, -1.4), (-1.3, -0.4)], 30, ("kink", "sausage")),
+    "CDC_w095_neg": ("CD-C", [], [0.6, 1.8, 3.0], [(-4.95, -2.05)], 40, ("kink", "sausage")),
 }
 
 
