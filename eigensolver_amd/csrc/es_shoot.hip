@@ -384,7 +384,10 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
   if (n_polish == 0) shoot_point<FAM>(P, k, root, root, D, rel, st, es_point_lds);
   for (int it = 0; it < n_polish; ++it) {
     double x = lo - flo * (hi - lo) / (fhi - flo);
-    if (!(x > lo && x < hi)) x = lo + (hi - lo) * 0.5;           // also catches NaN
+    // A secant point that rounding puts ON or just outside an end means that end is the root to the last bit (|f| there
+    // is rounding noise): stay at the end with the smaller |f| -- bisecting at that stage would throw the root half a
+    // bracket away.  Only a NaN estimate falls back to the mid-point.
+    if (!(x > lo && x < hi)) x = (x == x) ? ((fabs(flo) <= fabs(fhi)) ? lo : hi) : lo + (hi - lo) * 0.5;
     shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     root = x;
     if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }

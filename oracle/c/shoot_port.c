@@ -591,7 +591,8 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
     if (polish == 0) s = port_eval(P, kk, root, &d, &r);
     for (int it = 0; it < polish; ++it) {
       double x = lo - flo * (hi - lo) / (fhi - flo);
-      if (!(x > lo && x < hi)) x = lo + (hi - lo) * 0.5;
+      /* as the HIP refine_kernel: a secant point on / outside an end keeps the end with the smaller |f| */
+      if (!(x > lo && x < hi)) x = (x == x) ? ((fabs(flo) <= fabs(fhi)) ? lo : hi) : lo + (hi - lo) * 0.5;
       s = port_eval(P, kk, x, &d, &r);
       root = x;
       if (d * flo < 0.0) { hi = x; fhi = d; } else if (d == d) { lo = x; flo = d; }
