@@ -28,5 +28,6 @@ for name in ("fetch", "write", "sq"):
             out[cn] = {k: {"dispatches": len(v), key: sum(v) / len(v)} for k, v in d.items()}
 json.dump(out, open(os.path.join(pr, f"{tag}_bench_pmc.json"), "w"), indent=1)
 hbm = {k: out[k] for k in ("FETCH_SIZE", "WRITE_SIZE") if k in out}
+hbm["round"] = tag
 json.dump(hbm, open(os.path.join(pr, "bench_pmc_hbm_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
