@@ -20,6 +20,7 @@ def solver_factories():
         "CDC_uniform": ("CD-C", lambda ctx=None: E.CylinderNonUniformDensity(width=1e5, ctx=ctx)),
         "CDP": ("CD-P", lambda ctx=None: E.CylinderNonUniformDensity(width=0.9, photospheric=True, ctx=ctx)),
         "CRKF": ("CR-KF", lambda ctx=None: E.CylinderRotationalFlow(v_twist=0.25, power=0.8, variant="kink_fast", ctx=ctx)),
+        "CRKF_v01p1": ("CR-KF", lambda ctx=None: E.CylinderRotationalFlow(v_twist=0.1, power=1.0, variant="kink_fast", ctx=ctx)),
         "CRKS": ("CR-KS", lambda ctx=None: E.CylinderRotationalFlow(v_twist=0.1, power=0.8, variant="kink_slow", ctx=ctx)),
         "CRSF": ("CR-SF", lambda ctx=None: E.CylinderRotationalFlow(v_twist=0.15, power=1.25, variant="sausage", ctx=ctx)),
         "CRSS": ("CR-SS", lambda ctx=None: E.CylinderRotationalFlow(v_twist=0.15, power=1.25, variant="sausage_slow", ctx=ctx)),

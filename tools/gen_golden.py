@@ -231,6 +231,13 @@ ROOTSETS = {
     "SFG_flow_neg": ("SF-G", [("dx=1e5", "dx=1.5"), ("U_i0 = 0.9*vA_i", "U_i0 = 0.35*vA_i")],
                      [0.5, 1.5, 2.5], [(-2.45, -1.4), (-1.3, -0.4)], 30, ("kink", "sausage")),
     "CDC_w095_neg": ("CD-C", [], [0.6, 1.8, 3.0], [(-4.95, -2.05)], 40, ("kink", "sausage")),
+    # CR-KF with the parameters of one of its stored result files (vtwist01_power1): the checked-in 0.25 / 0.8 makes fsolve
+    # fail at most evaluations
+    "CRKF_v01p1": ("CR-KF", [("v_twist = 0.25", "v_twist = 0.1"), ("power = 0.8", "power = 1.0")],
+                   [0.6, 1.0, 1.5, 2.0, 2.5, 3.0], [(1.21, 1.44)], 30, ("kink",)),
+    # SD-P in the uniform limit (its benchmark case): body modes between cT_i0 and c_i0, away from every continuum
+    "SDP_uniform": ("SD-P", [("1e5)  # inside slab x values", "2001)  # inside slab x values")],
+                    [1.0, 2.0, 3.0], [(0.9, 0.99)], 20, ("kink", "sausage")),
 }
 
 
