@@ -348,15 +348,23 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
 // no longer the N = 1 table bit for bit.  The threshold below is far above any tile of the bench.)
 __host__ __device__ inline int refine_sections(long n_brackets) { return n_brackets <= 32768 ? 17 : 9; }
 
-template <int FAM, int LANES>
-__global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
+// Workgroups of 4 waves share ONE LDS staging of the (k-independent) base table: 3.6 KB of LDS per wave instead of 14.4,
+// so occupancy is no longer LDS-bound and the compiler aims for the register footprint of the point kernel -- which is
+// what lets refinement waves fit beside the grid kernel's when consecutive steps are pipelined over two streams.
+constexpr int REFINE_WAVES = 4;
+
+// WPE = 3 (<= 168 VGPRs: 165 for the untwisted cylinder, no spill; two grid waves of 168 and one refinement wave share a
+// SIMD's 512 registers) except for the twisted family, which needs 234 and would spill (WPE = 2).
+template <int FAM, int LANES, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+__global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
                                                     const double* __restrict__ d_hi, int n, int n_rounds,
                                                     int n_polish, double tol_percent) {
   ES_POINT_LDS(FAM);
   constexpr int GROUPS = 64 / LANES;
   const int lane = threadIdx.x & 63;
   const int g = lane / LANES, j = lane % LANES;
-  const int i = blockIdx.x * GROUPS + g;
+  const int i = (blockIdx.x * REFINE_WAVES + ((int)threadIdx.x >> 6)) * GROUPS + g;
   const bool in = i < n;
   const double k = in ? tab.d_k[i] : 1.0;
   double lo = in ? tab.d_w_lo[i] : 1.0;
@@ -364,33 +372,45 @@ __global__ __launch_bounds__(64) void refine_kernel(ShootDev P, es_root_table ta
   double flo = in ? d_lo[i] : 1.0;
   double fhi = in ? d_hi[i] : -1.0;
   const double frac = (double)(j + 1) / (double)(LANES + 1);
-  double D, rel; uint8_t st;
-  for (int it = 0; it < n_rounds; ++it) {
-    const double x = lo + (hi - lo) * frac;
+  double D = 0.0, rel = 0.0; uint8_t st = 0;
+  double root = lo;
+  // ONE evaluation site for the section rounds and the polish steps (the determinant evaluation is inlined: a single
+  // copy keeps the kernel at the register footprint of the point kernel plus the bracket state, so that refinement
+  // waves fit beside the grid kernel's when consecutive steps are pipelined over two streams)
+  const int n_final = (n_polish > 0) ? n_polish : 1;
+  for (int it = 0; it < n_rounds + n_final; ++it) {
+    const bool section = it < n_rounds;
+    double x;
+    if (section) {
+      x = lo + (hi - lo) * frac;
+    } else if (n_polish > 0) {
+      // Newton-type polish in fp64: regula-falsi (secant through the bracket ends), every lane of the group the same.
+      // A secant point that rounding puts ON or just outside an end means that end is the root to the last bit (|f|
+      // there is rounding noise): stay at the end with the smaller |f| -- bisecting at that stage would throw the
+      // root half a bracket away.  Only a NaN estimate falls back to the mid-point.
+      x = lo - flo * (hi - lo) / (fhi - flo);
+      if (!(x > lo && x < hi)) x = (x == x) ? ((fabs(flo) <= fabs(fhi)) ? lo : hi) : lo + (hi - lo) * 0.5;
+    } else {
+      x = lo + (hi - lo) * 0.5;                        // n_polish = 0: report the bracket mid-point
+    }
     shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
-    const bool diff = (D * flo < 0.0);                 // NaN products compare false, as in the reference
-    const unsigned long long bal = __ballot(diff);
-    const unsigned long long bits = (LANES == 64) ? bal : ((bal >> (LANES * g)) & ((1ull << (LANES & 63)) - 1ull));
-    const int first = bits ? (__ffsll((long long)bits) - 1) : LANES;     // first point whose sign differs from D(lo)
-    const int src_hi = g * LANES + (first < LANES ? first : LANES - 1);
-    const int src_lo = g * LANES + (first > 0 ? first - 1 : 0);
-    const double x_hi = __shfl(x, src_hi), d_hi_new = __shfl(D, src_hi);
-    const double x_lo = __shfl(x, src_lo), d_lo_new = __shfl(D, src_lo);
-    if (first < LANES) { hi = x_hi; fhi = d_hi_new; }
-    if (first > 0) { lo = x_lo; flo = (d_lo_new == d_lo_new) ? d_lo_new : flo; }
-  }
-  // Newton-type polish in fp64: regula-falsi (secant through the bracket ends) steps, every lane of the group the same
-  double root = lo + (hi - lo) * 0.5;
-  if (n_polish == 0) shoot_point<FAM>(P, k, root, root, D, rel, st, es_point_lds);
-  for (int it = 0; it < n_polish; ++it) {
-    double x = lo - flo * (hi - lo) / (fhi - flo);
-    // A secant point that rounding puts ON or just outside an end means that end is the root to the last bit (|f| there
-    // is rounding noise): stay at the end with the smaller |f| -- bisecting at that stage would throw the root half a
-    // bracket away.  Only a NaN estimate falls back to the mid-point.
-    if (!(x > lo && x < hi)) x = (x == x) ? ((fabs(flo) <= fabs(fhi)) ? lo : hi) : lo + (hi - lo) * 0.5;
-    shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
-    root = x;
-    if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }
+    if (section) {
+      const bool diff = (D * flo < 0.0);               // NaN products compare false, as in the reference
+      const unsigned long long bal = __ballot(diff);
+      const unsigned long long bits = (LANES == 64) ? bal : ((bal >> (LANES * g)) & ((1ull << (LANES & 63)) - 1ull));
+      const int first = bits ? (__ffsll((long long)bits) - 1) : LANES;     // first point whose sign differs from D(lo)
+      const int src_hi = g * LANES + (first < LANES ? first : LANES - 1);
+      const int src_lo = g * LANES + (first > 0 ? first - 1 : 0);
+      const double x_hi = __shfl(x, src_hi), d_hi_new = __shfl(D, src_hi);
+      const double x_lo = __shfl(x, src_lo), d_lo_new = __shfl(D, src_lo);
+      if (first < LANES) { hi = x_hi; fhi = d_hi_new; }
+      if (first > 0) { lo = x_lo; flo = (d_lo_new == d_lo_new) ? d_lo_new : flo; }
+    } else {
+      root = x;
+      if (n_polish > 0) {
+        if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }
+      }
+    }
   }
   if (in && j == 0) {
     tab.d_w[i] = root;
@@ -876,11 +896,11 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   int rounds = 0;
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
   if (sections == 17)
-    hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 3) / 4), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, d_hi,
-                       n, rounds, ES_REFINE_POLISH, tol);
+    hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, ES_REFINE_POLISH, tol);
   else
-    hipLaunchKernelGGL((refine_kernel<FAM, 8>), dim3((n + 7) / 8), dim3(64), 0, ctx->stream, prob->dev, tab, d_lo, d_hi,
-                       n, rounds, ES_REFINE_POLISH, tol);
+    hipLaunchKernelGGL((refine_kernel<FAM, 8>), dim3((n + 8 * REFINE_WAVES - 1) / (8 * REFINE_WAVES)),
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, ES_REFINE_POLISH, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
