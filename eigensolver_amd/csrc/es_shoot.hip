@@ -25,9 +25,16 @@ using namespace es_shoot_shared;
 // ------------------------------------------------------------------------------------------------------------
 // Options of one grid launch: skip = ES_EVAL_SKIP_CONTINUUM; cols != nullptr: only the omega-columns cols[1 .. cols[0]]
 // are evaluated (live-column list built on the device by column_classify_kernel), the others were filled beforehand.
+// part (compacted launches only): 0 = every segment; 1 = the full segments of a row; 2 = the columns behind the last
+// full segment of width main_span, in segments of this launch's own (narrower) workgroups.  A partly filled segment in
+// a 4-wave workgroup costs as much as a full one: its live wave shares a SIMD with two waves of other workgroups, and
+// those workgroups are tied by their barriers to the pace of that SIMD, so the idle wave slots buy nothing; given to
+// one-wave workgroups of a second launch, the remainder costs what its waves cost.
 struct GridOpts {
   int skip;
   const int* cols;
+  int part;
+  int main_span;
 };
 
 template <int FAM, int PTS, int MAXT, bool TRACK, int WPE = 0>
@@ -52,13 +59,21 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
   // tile = (k-row, omega-segment of T*PTS points): rows wider than one segment are split across workgroups, so the
   // number of workgroups is nk * nseg (narrow k-tiles of a multi-GPU run still fill the chip, and the tail of the
   // launch is one segment long instead of one row)
-  const int nseg = (nw + T * PTS - 1) / (T * PTS);
-  const long ntiles = (long)nk * nseg;
+  const int span = T * PTS;
   const int ncols = opts.cols ? opts.cols[0] : nw;     // columns to evaluate (workgroup-uniform)
+  const int col_base = (opts.part == 2) ? (ncols / opts.main_span) * opts.main_span : 0;
+  const int nseg = (opts.part == 2) ? opts.main_span / span : (nw + span - 1) / span;
+  const long ntiles = (long)nk * nseg;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row = (int)(tile / nseg);
-    const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
+    // segment-major order: consecutive workgroup ids (dealt round-robin to the 8 XCDs) are consecutive k-rows of one
+    // omega-segment.  With the row-major order tile = row * nseg + segment and nseg = 4, segment s of every row went to
+    // XCDs s and s + 4: segments whose points are dead (continuum, leaky) or absent (compacted launch) idled two XCDs
+    // while the other six carried the launch
+    const int seg = (int)(tile / nk);
+    const int row = (int)(tile - (long)seg * nk);
+    const int w0 = col_base + seg * span;
     if (w0 >= ncols) continue;                         // segment beyond the live columns
+    if (opts.part == 1 && w0 + span > ncols) continue; // partly filled segment: left to the remainder launch
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
     {
@@ -563,8 +578,9 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
   const int nseg = (nw + T * PTS - 1) / (T * PTS);
   const long ntiles = (long)nk * nseg;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row = (int)(tile / nseg);
-    const int w0 = (int)(tile - (long)row * nseg) * T * PTS;
+    const int seg = (int)(tile / nk);                  // segment-major, as in shoot_grid_kernel (XCD balance)
+    const int row = (int)(tile - (long)seg * nk);
+    const int w0 = seg * T * PTS;
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
     v2f wf[NP], zp[NP], zq[NP];
@@ -813,6 +829,8 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   GridOpts opts;
   opts.skip = (flags & ES_EVAL_SKIP_CONTINUUM) ? 1 : 0;
   opts.cols = nullptr;
+  opts.part = 0;
+  opts.main_span = 0;
   if (opts.skip && w_mode == ES_W_PHASE_SPEED && fam_has_bands<FAM>() && prob->dev.use_bands) {
     // live-column list on the device, dead columns filled at once; the grid launch below is sized for all nw
     // columns (the count stays on the device), workgroups beyond the live ones return immediately
@@ -861,7 +879,18 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   if (variant == 3) {
     if constexpr (FAM == FAM_CYL0) {
       const int T = roundT((nw + 3) / 4, 256);
-      ES_LAUNCH_GRID_W(4, 256, T, 3);
+      if (opts.cols && T > 64) {
+        // compacted launch: full segments in 4-wave workgroups, the remainder of each row in one-wave workgroups
+        opts.part = 1;
+        ES_LAUNCH_GRID_W(4, 256, T, 3);
+        opts.part = 2;
+        opts.main_span = 4 * T;
+        const long tiles2 = (long)nk * (T / 64);
+        hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 64, false, 2>), dim3((int)(tiles2 < (1L << 22) ? tiles2 : (1L << 22))),
+                           dim3(64), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
+      } else {
+        ES_LAUNCH_GRID_W(4, 256, T, 3);
+      }
     }
   } else if (variant == 1) {
     const int T = roundT((nw + 3) / 4, 512);

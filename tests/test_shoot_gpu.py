@@ -365,7 +365,8 @@ def test_node_count_extremes_cylinder(es_ctx, n_nodes):
 
 
 @pytest.mark.parametrize("name,w_mode", [("CF_flow_kink", 1), ("CF_flow_sausage", 1), ("CDC_w095_kink", 1), ("CF_flow_m3", 1),
-                                         ("SD_w15_kink", 1), ("SFG_flow_kink", 1), ("CR_kink", 1), ("CF_flow_kink", 2)])
+                                         ("SD_w15_kink", 1), ("SFG_flow_kink", 1), ("CR_kink", 1), ("CF_flow_kink", 2),
+                                         ("CF_flow_kink", 3)])
 def test_skip_continuum_flag(es_ctx, name, w_mode):
     """es_shoot_eval_grid_ex(ES_EVAL_SKIP_CONTINUUM): statuses as without the flag; D and rel bit-identical at every
     point that is not ES_PT_CONTINUUM, NaN at the continuum points; with ES_W_PHASE_SPEED whole columns inside a band
@@ -376,6 +377,10 @@ def test_skip_continuum_flag(es_ctx, name, w_mode):
     gp = _gpu_problem(es_ctx, case)
     k = np.linspace(0.3, 3.9, 5)
     nw = 1500 if name == "CF_flow_kink" else 333
+    if w_mode == 3:
+        # rows of >= 2048 points: the 256-thread x 4-point launch shape, whose compacted form is two launches (full
+        # segments in 4-wave workgroups, the remainder of every row in one-wave workgroups)
+        w_mode, nw = 1, 2600
     if name.startswith("CF_flow"):
         lo = 0.9                          # include the cusp and Alfven bands of the flow profile
     W = np.linspace(lo, hi, nw)
