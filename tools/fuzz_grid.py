@@ -42,6 +42,8 @@ def main(n_cases, seed=5):
     for c in range(n_cases):
         eq, mode, m, (lo, hi) = random_problem(rng)
         nk, nw = int(rng.integers(2, 9)), int(rng.integers(40, 400))
+        if rng.uniform() < 0.2:               # wide rows: the 4-points-per-lane launch shapes, several segments per row
+            nk, nw = int(rng.integers(2, 4)), int(rng.integers(1024, 5200))
         k = np.sort(rng.uniform(0.05, 4.2, nk))
         a, b = np.sort(rng.uniform(lo, hi, 2))
         if b - a < 0.05 * (hi - lo):
