@@ -199,6 +199,10 @@ def main():
                     help="config3 (default, the headline): BASELINE.json configs[3]; config4: configs[4], Cylinder / "
                          "rotational flow, m = 0..10, fp32 bracket + fp64 refine (a second, never the headline, line)")
     ap.add_argument("--precision", choices=("mixed", "f64"), default="mixed", help="config4 only")
+    ap.add_argument("--share-of", type=int, default=1,
+                    help="N = 1 only, a projection aid and never the judged line: this process computes what rank 0 of a "
+                         "--gpus E strong-scaling run computes (k-rows 0, E, 2E, ... and the packing of its exchange "
+                         "buffer, no collective); the line carries `emulated_share_of` and `projected_whole_job_value`")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -238,7 +242,8 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     strong = a.mode == "strong"
     m = 1 if strong else rank + 1                  # weak-m: rank r owns azimuthal order m = r + 1
-    rows_np = D.tile_rows(NK, rank, world, strided=True) if strong else np.arange(NK)
+    share = a.share_of if (world == 1 and strong and a.share_of > 1) else 1
+    rows_np = D.tile_rows(NK, rank, world * share, strided=True) if strong else np.arange(NK)
     rows_t = torch.as_tensor(rows_np, device=dev)
     k = torch.as_tensor(k_np[rows_np], dtype=torch.float64, device=dev)
     W = torch.as_tensor(W_np, dtype=torch.float64, device=dev)
@@ -280,7 +285,7 @@ def main():
                 tail.record(stream)
                 grid_tail[0] = tail
             roots, nbr = pr.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=tb)
-            send = D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP, ctx=cx) if world > 1 else None
+            send = D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP, ctx=cx) if (world > 1 or share > 1) else None
             done = torch.cuda.Event()
             done.record(stream)
         return roots, nbr, send, st, done
@@ -340,7 +345,7 @@ def main():
 
     # the other mode of the grid evaluation, a few steps outside the timed region (N = 1 only): reported, never `value`
     other = None
-    if world == 1 and not a.no_extra_mode:
+    if world == 1 and share == 1 and not a.no_extra_mode:
         st_main = st
         skip = not skip
         step()
@@ -450,6 +455,11 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu
+        if share > 1:
+            out["emulated_share_of"] = share
+            out["projected_whole_job_value"] = value * share
+            out["config"]["parallelism"] = (f"PROJECTION: one GPU computing rank 0's tile of a {share}-GPU strong-scaling run "
+                                            f"(every {share}th k-row, exchange buffer packed, no collective)")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
