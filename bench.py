@@ -315,7 +315,6 @@ def main():
         finally:
             free_lanes.put(j)
 
-    unshared = []                                   # grid launches of the warm-up: nothing else on the chip
     for _ in range(a.warmup):
         for j in range(n_lanes):
             e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -323,7 +322,18 @@ def main():
             if world > 1:
                 exchange(send_w, done_w)            # also brings the communicator up before the timed region
             torch.cuda.synchronize()
-            unshared.append(e[0].elapsed_time(e[1]))
+    # the dominant kernel alone on a busy chip: grid launches back to back on one stream, the first one not counted (a
+    # launch that follows idle time runs up to 13 % slower while the clocks ramp: tools/probe/time_small_launches.py)
+    alone = []
+    with torch.cuda.stream(lanes[0][0]):
+        for _ in range(4):
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e[0].record(lanes[0][0])
+            prob.eval_grid(k, W, skip_continuum=skip)
+            e[1].record(lanes[0][0])
+            alone.append(e)
+    torch.cuda.synchronize()
+    unshared = [e0.elapsed_time(e1) for e0, e1 in alone[1:]]
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     pool = ThreadPoolExecutor(max_workers=n_lanes) if n_lanes > 1 else None
     if world > 1:
@@ -442,14 +452,14 @@ def main():
                          "algorithmic_bytes_per_launch": launch_evals * BYTES_PER_EVAL,
                          "bytes_per_launch_incl_status": launch_evals * BYTES_PER_EVAL_WITH_STATUS,
                          "evals_per_launch": launch_evals, "avg_launch_ms": grid_ms,
-                         "avg_launch_ms_unshared": (float(np.mean(unshared[1:] or unshared)) if unshared else None),
+                         "avg_launch_ms_unshared": (float(np.mean(unshared)) if unshared else None),
                          "launch_note": "avg_launch_ms: HIP events around every grid launch of the timed region; with "
                                         "--streams 2 the previous step's refinement shares the chip with it. "
-                                        "avg_launch_ms_unshared: the same launch alone on the chip (warm-up passes)",
+                                        "avg_launch_ms_unshared: the same launch alone on a busy chip (back-to-back launches before the timed region)",
                          "note": "fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
             "valu_fp64": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": tflops / FP64_VALU_PEAK_TFLOPS,
-                          "frac_unshared": (tflops * grid_ms / float(np.mean(unshared[1:] or unshared)) / FP64_VALU_PEAK_TFLOPS
+                          "frac_unshared": (tflops * grid_ms / float(np.mean(unshared)) / FP64_VALU_PEAK_TFLOPS
                                             if unshared else None),
                           "flops_per_eval": FLOPS_PER_STEP * nsteps},
         }
