@@ -372,8 +372,7 @@ constexpr int REFINE_WAVES = 4;
 // SIMD's 512 registers) except for the twisted family, which needs 234 and would spill (WPE = 2).
 template <int FAM, int LANES, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_lo,
-                                                    const double* __restrict__ d_hi, int n, int n_rounds,
+void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, int n, int n_rounds,   // d_lo / d_hi alias table columns
                                                     int n_polish, double tol_percent) {
   ES_POINT_LDS(FAM);
   constexpr int GROUPS = 64 / LANES;
@@ -392,7 +391,7 @@ void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_l
   // ONE evaluation site for the section rounds and the polish steps (the determinant evaluation is inlined: a single
   // copy keeps the kernel at the register footprint of the point kernel plus the bracket state, so that refinement
   // waves fit beside the grid kernel's when consecutive steps are pipelined over two streams)
-  const int n_final = (n_polish > 0) ? n_polish : 1;
+  const int n_final = (n_polish > 0) ? n_polish : (n_polish == 0 ? 1 : 0);
   for (int it = 0; it < n_rounds + n_final; ++it) {
     const bool section = it < n_rounds;
     double x;
@@ -428,6 +427,43 @@ void refine_kernel(ShootDev P, es_root_table tab, const double* __restrict__ d_l
     }
   }
   if (in && j == 0) {
+    tab.d_w_lo[i] = lo;
+    tab.d_w_hi[i] = hi;
+    if (n_polish < 0) {                                // section rounds only: D at the ends goes on to refine_polish_kernel
+      d_lo[i] = flo;
+      d_hi[i] = fhi;
+    } else {
+      tab.d_w[i] = root;
+      tab.d_resid[i] = rel;
+      tab.d_flag[i] = (st == ES_PT_OK && rel < tol_percent) ? 1 : 0;
+    }
+  }
+}
+
+// The polish steps of refine_kernel with ONE lane per bracket (same arithmetic, bit for bit): in refine_kernel all LANES
+// lanes of a bracket evaluate the same secant point, so two of its six marches do a sixteenth of the work they cost.
+template <int FAM, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+__global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void refine_polish_kernel(ShootDev P, es_root_table tab, const double* d_lo, const double* d_hi, int n, int n_polish,
+                          double tol_percent) {                      // d_lo / d_hi alias table columns (no restrict)
+  ES_POINT_LDS(FAM);
+  const int i = blockIdx.x * (64 * REFINE_WAVES) + (int)threadIdx.x;
+  const bool in = i < n;
+  const double k = in ? tab.d_k[i] : 1.0;
+  double lo = in ? tab.d_w_lo[i] : 1.0;
+  double hi = in ? tab.d_w_hi[i] : 2.0;
+  double flo = in ? d_lo[i] : 1.0;
+  double fhi = in ? d_hi[i] : -1.0;
+  double D = 0.0, rel = 0.0; uint8_t st = 0;
+  double root = lo;
+  for (int it = 0; it < n_polish; ++it) {
+    double x = lo - flo * (hi - lo) / (fhi - flo);
+    if (!(x > lo && x < hi)) x = (x == x) ? ((fabs(flo) <= fabs(fhi)) ? lo : hi) : lo + (hi - lo) * 0.5;
+    shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
+    root = x;
+    if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }
+  }
+  if (in) {
     tab.d_w[i] = root;
     tab.d_w_lo[i] = lo;
     tab.d_w_hi[i] = hi;
@@ -918,19 +954,27 @@ int launch_points(es_context* ctx, const es_problem* prob, const double* d_k, co
 }
 
 template <int FAM>
-int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const double* d_lo,
-                  const double* d_hi, int n, int n_bisect, double tol) {
+int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, double* d_lo, double* d_hi, int n,
+                  int n_bisect, double tol) {
   // (LANES+1)-section rounds equivalent to n_bisect halvings: (LANES+1)^R >= 2^n_bisect
   const int sections = refine_sections(n);
   int rounds = 0;
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
+  // section rounds with LANES lanes per bracket, then the polish steps with one lane per bracket (d_lo / d_hi carry D at
+  // the ends of the narrowed bracket from one kernel to the other)
+  const int np = (ES_REFINE_POLISH > 0 && rounds > 0) ? -1 : ES_REFINE_POLISH;
   if (sections == 17)
     hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, ES_REFINE_POLISH, tol);
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
   else
     hipLaunchKernelGGL((refine_kernel<FAM, 8>), dim3((n + 8 * REFINE_WAVES - 1) / (8 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, ES_REFINE_POLISH, tol);
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
+  if (np < 0) {
+    hipLaunchKernelGGL((refine_polish_kernel<FAM>), dim3((n + 64 * REFINE_WAVES - 1) / (64 * REFINE_WAVES)),
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, ES_REFINE_POLISH, tol);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+  }
   return ES_SUCCESS;
 }
 
