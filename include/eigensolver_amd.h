@@ -186,8 +186,8 @@ typedef struct es_root_table {
 /* Grid search: brackets = sign changes of D between omega-neighbours of the same row with both ends ES_PT_OK
  * (wavefront shuffle + ballot, ordered compaction: rows outer, omega inner); each bracket is narrowed at least
  * as far as `n_bisect` bisection steps would (the reference's 3-point linspace refinement, e.g. :823-829, run to
- * convergence; executed as ceil(n_bisect*ln2/ln9) rounds of 9-section, 8 lanes per bracket, always keeping the
- * sign change nearest to the lower end), then polished in fp64 by two regula-falsi steps (the secant through the
+ * convergence; executed as rounds of 17-section with 16 lanes per bracket -- 9-section with 8 lanes beyond 32768
+ * brackets -- as many as shrink the bracket by 2^n_bisect, always keeping the sign change nearest to the lower end), then polished in fp64 by two regula-falsi steps (the secant through the
  * bracket ends: the Newton-type refinement of the north star, without a derivative of D) and classified with the
  * reference's acceptance rule rel < tol_percent at the last secant point, which is the root reported;
  * [w_lo, w_hi] is the final bracket around it.
