@@ -178,6 +178,17 @@ def test_roots_vs_port(es_ctx, name):
     assert np.all(np.diff(g["row"]) >= 0)
     same = np.diff(g["row"]) == 0
     assert np.all(np.diff(g["w"])[same] > 0)
+    # shallow refinements: no section round at all (polish steps inside refine_kernel) and a single round followed by
+    # the one-lane polish kernel -- the port's table value for value
+    for nb in (0, 3):
+        r2, c2 = gp.find_roots(k, W, D, st, n_bisect=nb, tol_percent=1e-4)
+        p2, cp2 = port.find_roots(k, W, Dp, stp, w_mode=1, n_bisect=nb, tol=1e-4, nthreads=8)
+        assert c2 == cp2 == cnt
+        g2 = {n_: v.cpu().numpy() for n_, v in r2.items()}
+        assert np.array_equal(g2["flag"], p2["flag"]), (name, nb)
+        d2 = np.abs(g2["w"] - p2["w"]) / np.abs(p2["w"])
+        assert d2.max() < 1e-9, (name, nb, d2.max())       # unconverged estimates: differences of the 1e-12 D amplified by the secant
+        assert np.all((g2["w_lo"] <= g2["w"]) & (g2["w"] <= g2["w_hi"]))
     gp.close()
 
 
