@@ -63,7 +63,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 BYTES_PER_EVAL = 8.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 BYTES_PER_EVAL_WITH_STATUS = BYTES_PER_EVAL + 1.0
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-FLOPS_PER_STEP = 2 * 9 + 8 + 28             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step in the scaled-coefficient form (8 fma, 2 fma-by-2, 6 add, 2 mul = 28)
+FLOPS_PER_STEP = 2 * 9 + 8 + 26             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step in the scaled-coefficient form without the division by 3 (8 fma, 2 fma-by-2, 6 add = 26)
 
 
 def workload_equilibrium():

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void eigen_interior_kernel(ShootDev P, const do
     load_base<FAM>(P, 2 * j, b);
     make_entry<FAM, fam_scaled<FAM>()>(b, s, e2);
     coefficients2<FAM>(e, e2, P, s, w, Bm, B1, trk);
-    adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);      // same arithmetic as the determinant kernels
+    adjoint_step_normalised<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);      // z at its true scale
     B0 = B1;
   }
   // boundary state from the same algebra as the determinant
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(64) void eigen_interior_kernel(ShootDev P, const do
   if (FAM == FAM_CYL0 || FAM == FAM_CYLT) {
     ub = X.yb;
     const double xi_e = X.outer;
-    if (P.axis_bc == ES_AXIS_KINK) vb = (P.bc_const * xi_e - zp * ub) / zq;
-    else if (P.axis_bc == ES_AXIS_ROTATION_KINK) vb = (-(P.bc_const * xi_e) - zp * ub) / zq;
+    if (P.axis_bc == ES_AXIS_KINK) vb = (P.bc_const_raw * xi_e - zp * ub) / zq;
+    else if (P.axis_bc == ES_AXIS_ROTATION_KINK) vb = (-(P.bc_const_raw * xi_e) - zp * ub) / zq;
     else vb = -(zp * ub) / zq;
     flux_scale = 1.0;            // xi = Xi / r, applied per node
   } else if (FAM == FAM_SLABD) {

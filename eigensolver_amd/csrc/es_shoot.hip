@@ -172,6 +172,8 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
           }
         }
 #undef ES_MARCH_STEP
+#pragma unroll
+        for (int p = 0; p < PTS; ++p) adjoint_rescale<FAM>(zp[p], zq[p], nst);
       }
       if (STASH) {
 #pragma unroll
@@ -731,7 +733,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       // r = (r1, r2) * 2^zexp: the common factor multiplies the homogeneous part of the axis condition; its target
       // (bc_const * xi_e, non-zero only for the twisted kink condition) is divided by it instead
       ShootDev Pl = P;
-      Pl.bc_const = P.bc_const * ldexp(1.0, -zexp[p]);
+      Pl.bc_const = P.bc_const_raw * ldexp(1.0, -zexp[p]);
       const Mismatch M = boundary_algebra<FAM>(Pl, s, w, X, (double)zpp, (double)zqq, ef);
       // watched terms: certain sign / certain crossing / unsure (see ScreenF)
       const float S = F32_TAU_NODE * (float)(w * w + ef[1]);
@@ -1079,7 +1081,20 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
   S.ic0 = d->ic_value;
   S.ic1 = d->ic_slope;
   S.m = d->m; S.m_ext = d->m_ext; S.axis_bc = d->axis_bc; S.c1_power = d->c1_power;
-  S.bc_const = d->bc_const;
+  S.bc_const = S.bc_const_raw = d->bc_const;
+  if (d->geometry == FAM_CYL0 && d->bc_const != 0.0) {
+    // the fp64 marches of this family deliver z times adjoint_scale (a factor 3 per step, an exact power of two back per
+    // LDS chunk): a non-zero target of the axis condition carries the same factor
+    double c = 1.0;
+    const int nsteps = N - 1;
+    for (int ch = (nsteps + es_shoot_shared::CH - 1) / es_shoot_shared::CH - 1; ch >= 0; --ch) {
+      const int c0 = ch * es_shoot_shared::CH;
+      const int nst = (nsteps - c0 < es_shoot_shared::CH) ? (nsteps - c0) : es_shoot_shared::CH;
+      for (int i = 0; i < nst; ++i) c *= 3.0;
+      c = ldexp(c, adjoint_rescale_exp(nst));
+    }
+    S.bc_const = d->bc_const * c;
+  }
   S.slab_sign = (d->slab_mode == ES_SLAB_MODE_SAUSAGE) ? -1.0 : 1.0;
   S.c2_i = d->c_i * d->c_i;
   S.vA2_i = d->vA_i * d->vA_i;

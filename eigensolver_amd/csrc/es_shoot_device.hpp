@@ -39,7 +39,8 @@ struct ShootDev {
   double ic0, ic1;    // far-field initial values of the reference's exterior solve
   // cylinder
   int m, m_ext, axis_bc, c1_power;
-  double bc_const;
+  double bc_const;     // as the fp64 marches need it: for the unnormalised family times the scale their z carries (adjoint_scale)
+  double bc_const_raw; // as given (fp32 march, eigenfunction kernel: z at its true scale)
   // slab
   double slab_sign;   // -1 sausage: Vx(+1) = -Vx(-1);  +1 kink
   double c2_i, vA2_i, S_i, cT2_i, rho_i;   // uniform interior speeds of the flow slab
@@ -352,9 +353,49 @@ __device__ __forceinline__ void rk4_step_adjoint_scaled0(double& p, double& q, c
   q = fma(B1.a12, tp3, sq) * third;
 }
 
+// The determinant needs the row z only up to a common factor (the far-end condition of the untwisted cylinder is
+// homogeneous: D depends on z_p / z_q; a non-zero target is multiplied by the same factor, see adjoint_scale), so the
+// marches of that family drop the division by 3: 3 z' = t1 + 2 t2 + t3 - z + A1^T t3 -- 16 instructions per step
+// instead of 18.  z then grows by 3 per step and is brought back by an exact power of two at the end of every LDS
+// chunk: adjoint_rescale(nst) = 2^-floor(nst log2 3) after nst steps.
+__device__ __forceinline__ void rk4_step_adjoint_scaled0_x3(double& p, double& q, const Coef& B0, const Coef& Bm,
+                                                            const Coef& B1) {
+  const double tp1 = fma(B0.a21, q, p),   tq1 = fma(B0.a12, p, q);
+  const double tp2 = fma(Bm.a21, tq1, p), tq2 = fma(Bm.a12, tp1, q);
+  const double am2 = Bm.a21 + Bm.a21,     bm2 = Bm.a12 + Bm.a12;
+  const double tp3 = fma(am2, tq2, p),    tq3 = fma(bm2, tp2, q);
+  const double sp = fma(2.0, tp2, tp1 + tp3) - p;
+  const double sq = fma(2.0, tq2, tq1 + tq3) - q;
+  p = fma(B1.a21, tq3, sp);
+  q = fma(B1.a12, tp3, sq);
+}
+
+// families whose fp64 marches carry z times a known factor (rk4_step_adjoint_scaled0_x3)
+template <int FAM> constexpr bool fam_unnormalised() { return FAM == FAM_CYL0; }
+
+__host__ __device__ inline int adjoint_rescale_exp(int nst) { return -(int)((double)nst * 1.5849625007211561); }   // -floor(nst log2 3)
+
+template <int FAM>
+__device__ __forceinline__ void adjoint_rescale(double& p, double& q, int nst) {
+  if (fam_unnormalised<FAM>()) {
+    const int ex = adjoint_rescale_exp(nst);
+    p = ldexp(p, ex);
+    q = ldexp(q, ex);
+  }
+}
+
 template <int FAM>
 __device__ __forceinline__ void adjoint_step(double& p, double& q, const Coef& B0, const Coef& Bm, const Coef& B1,
                                              double h, double h2, double h6, double h3) {
+  if (fam_unnormalised<FAM>()) rk4_step_adjoint_scaled0_x3(p, q, B0, Bm, B1);
+  else if (fam_scaled<FAM>()) rk4_step_adjoint_scaled0(p, q, B0, Bm, B1);
+  else rk4_step_adjoint<FamTraits<FAM>::SHAPE>(p, q, B0, Bm, B1, h, h2, h6, h3);
+}
+
+// the same step with z kept at its true scale (eigenfunction kernel)
+template <int FAM>
+__device__ __forceinline__ void adjoint_step_normalised(double& p, double& q, const Coef& B0, const Coef& Bm, const Coef& B1,
+                                                        double h, double h2, double h6, double h3) {
   if (fam_scaled<FAM>()) rk4_step_adjoint_scaled0(p, q, B0, Bm, B1);
   else rk4_step_adjoint<FamTraits<FAM>::SHAPE>(p, q, B0, Bm, B1, h, h2, h6, h3);
 }

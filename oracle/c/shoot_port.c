@@ -25,6 +25,8 @@
 #endif
 #include "../../include/eigensolver_amd.h"
 
+#define PORT_CH 128                                     /* es_shoot_shared::CH */
+static int port_rescale_exp(int nst) { return -(int)((double)nst * 1.5849625007211561); }   /* adjoint_rescale_exp */
 #define PI 3.14159265358979323846264338327950288
 #define EULER 0.57721566490153286060651209008240243
 
@@ -156,6 +158,16 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
   P->R_factor = d->L_factor * 2.0 * 3.14159265358979323846;
   P->ic0 = d->ic_value; P->ic1 = d->ic_slope;
   P->m = d->m; P->m_ext = d->m_ext; P->axis_bc = d->axis_bc; P->c1_power = d->c1_power; P->bc_const = d->bc_const;
+  if (d->geometry == ES_GEOM_CYLINDER && d->bc_const != 0.0) {   /* the factor the unnormalised march leaves on z (es_problem_create) */
+    double c = 1.0;
+    const int nsteps = N - 1;
+    for (int ch = (nsteps + PORT_CH - 1) / PORT_CH - 1; ch >= 0; --ch) {
+      const int c0 = ch * PORT_CH, nst = (nsteps - c0 < PORT_CH) ? (nsteps - c0) : PORT_CH;
+      for (int i = 0; i < nst; ++i) c *= 3.0;
+      c = ldexp(c, port_rescale_exp(nst));
+    }
+    P->bc_const = d->bc_const * c;
+  }
   P->slab_sign = (d->slab_mode == ES_SLAB_MODE_SAUSAGE) ? -1.0 : 1.0;
   P->c2_i = d->c_i * d->c_i; P->vA2_i = d->vA_i * d->vA_i; P->S_i = P->c2_i + P->vA2_i;
   P->cT2_i = (P->S_i > 0.0) ? P->c2_i * P->vA2_i / P->S_i : 0.0;
@@ -345,9 +357,10 @@ static void rk4_adjoint_scaled0(double* p, double* q, const coef* B0, const coef
   const double tp3 = fma(am2, tq2, *p), tq3 = fma(bm2, tp2, *q);
   const double sp = fma(2.0, tp2, tp1 + tp3) - *p;
   const double sq = fma(2.0, tq2, tq1 + tq3) - *q;
-  const double third = 1.0 / 3.0;
-  *p = fma(B1->a21, tq3, sp) * third;
-  *q = fma(B1->a12, tp3, sq) * third;
+  /* rk4_step_adjoint_scaled0_x3: no division by 3 (D depends on z_p / z_q only); the factor 3 per step is taken back by
+     an exact power of two at the end of every chunk of PORT_CH steps, as in the HIP kernels */
+  *p = fma(B1->a21, tq3, sp);
+  *q = fma(B1->a12, tp3, sq);
 }
 
 static void rk4_adjoint(int diag, double* p, double* q, const coef* B0, const coef* Bm, const coef* B1, double h,
@@ -468,6 +481,11 @@ static int port_eval_core(const port_problem* P, double k, double w, double w_cs
     if (P->family == 0) rk4_adjoint_scaled0(&zp, &zq, &B0, &Bm, &B1);
     else rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
     B0 = B1;
+    if (P->family == 0 && j % PORT_CH == 0) {          /* end of an LDS chunk of the HIP march: adjoint_rescale */
+      const int nst = (nsteps - j < PORT_CH) ? (nsteps - j) : PORT_CH;
+      const int ex = port_rescale_exp(nst);
+      zp = ldexp(zp, ex); zq = ldexp(zq, ex);
+    }
   }
   exterior X = (P->family <= 1) ? ext_cyl(P, k, w, w_cst) : ext_slab(P, k, w);
   if (ext_override && X.status == ES_PT_OK) {
