@@ -81,3 +81,29 @@ def test_numpy_grid_matches_port():
         assert ok.sum() > 200
         scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
         assert np.max(np.abs(Dp[ok] - Dn[ok]) / scale) < 1e-10
+
+
+def test_port_unnormalised_march_compensates_axis_target():
+    """The port (as the HIP marches of the untwisted cylinder) carries 3^n z with a power-of-two rescale per 128 steps and
+    multiplies a non-zero target of the axis condition, bc_const * xi_e, by the same factor.  The reference's own
+    profiles never have one for this family (B_phi = 0), so it is forced here and checked against the NumPy
+    restatement, whose march keeps z at its true scale: |dD| <= 1e-10 of the scale, for a node count that is not a
+    multiple of the chunk."""
+    import numpy as np
+    from eigensolver_amd import equilibrium as q, shooting as s
+    from oracle.grid_numpy import CylinderGrid
+    from oracle.port import PortProblem
+    eq = q.CylinderFlow(U_i0=0.4, width=0.9, n_nodes=331)
+    d, prof = s.make_desc(eq, "kink", 1)
+    desc = {f[0]: getattr(d, f[0]) for f in d._fields_}
+    k = np.array([0.3, 1.7, 3.6])
+    W = 0.95 + (np.arange(160) + 0.5) * (4.0 / 160)
+    base = PortProblem(desc, prof).eval_grid(k, W, w_mode=1, nthreads=2)
+    desc["bc_const"] = 0.37
+    Dp, relp, stp = PortProblem(desc, prof).eval_grid(k, W, w_mode=1, nthreads=2)
+    Dn, reln, stn = CylinderGrid(desc, {a: np.asarray(v) for a, v in prof.items()}).eval_grid(k, W)
+    ok = (stp == 0) & (stn == 0)
+    assert ok.sum() > 200
+    scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
+    assert np.max(np.abs(Dp[ok] - Dn[ok]) / scale) < 1e-10
+    assert np.max(np.abs(Dp[ok] - base[0][ok]) / scale) > 1e-3          # the target does enter D

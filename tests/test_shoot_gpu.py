@@ -49,6 +49,59 @@ def test_grid_vs_port(es_ctx, name):
     gp.close()
 
 
+@pytest.mark.parametrize("n_nodes", [2, 3, 129, 130, 20001])
+def test_unnormalised_march_node_counts(es_ctx, n_nodes):
+    """The marches of the untwisted cylinder carry 3^n z and take the factor back by an exact power of two per LDS
+    chunk of 128 steps: node counts of one step, one chunk +- one step and 157 chunks (3^20000 would overflow ten times
+    over without the rescaling) against the port, which rescales at the same nodes; and D must not depend on the
+    scale: the fine march agrees with the 1001-node march to the RK4 truncation error."""
+    from eigensolver_amd import ShootProblem, equilibrium as q
+    eq = q.CylinderFlow(U_i0=0.35, width=0.9, n_nodes=n_nodes)
+    k = np.array([0.7, 2.3])
+    W = np.linspace(0.95, 4.9, 96)
+    for mode, m in (("kink", 1), ("sausage", 0)):
+        gp = ShootProblem(eq, mode, m, ctx=es_ctx)
+        D, st, rel = (t.cpu().numpy() for t in gp.eval_grid(k, W, want_rel=True))
+        Dp, relp, stp = cases.port_problem(eq, mode, m).eval_grid(k, W, w_mode=1, nthreads=8)
+        assert np.array_equal(st, stp)
+        ok = st == 0
+        assert ok.sum() > 40 and np.all(np.isfinite(D[ok]))
+        scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
+        assert (np.abs(D[ok] - Dp[ok]) / scale).max() < D_RTOL
+        if n_nodes == 20001:
+            eq1 = q.CylinderFlow(U_i0=0.35, width=0.9, n_nodes=1001)
+            g1 = ShootProblem(eq1, mode, m, ctx=es_ctx)
+            D1, st1, rel1 = (t.cpu().numpy() for t in g1.eval_grid(k, W, want_rel=True))
+            both = ok & (st1 == 0)
+            sc = np.abs(D1[both]) * 100.0 / rel1[both]
+            assert np.median(np.abs(D[both] - D1[both]) / sc) < 1e-7
+            g1.close()
+        gp.close()
+
+
+def test_unnormalised_march_axis_target(es_ctx):
+    """A non-zero target of the axis condition (bc_const, forced: the untwisted profiles of the reference have none) is
+    multiplied at es_problem_create by the factor the unnormalised march leaves on z: GPU against the port, which is
+    checked against a normalised march in tests/test_oracle_port.py."""
+    from eigensolver_amd import ShootProblem, equilibrium as q
+
+    class Forced(q.CylinderFlow):
+        def bc_const(self, axis_bc):
+            return 0.37
+
+    eq = Forced(U_i0=0.4, width=0.9, n_nodes=331)
+    k = np.array([0.3, 1.7, 3.6])
+    W = 0.95 + (np.arange(160) + 0.5) * (4.0 / 160)
+    gp = ShootProblem(eq, "kink", 1, ctx=es_ctx)
+    D, st, rel = (t.cpu().numpy() for t in gp.eval_grid(k, W, want_rel=True))
+    Dp, relp, stp = cases.port_problem(eq, "kink", 1).eval_grid(k, W, w_mode=1, nthreads=8)
+    assert np.array_equal(st, stp)
+    ok = st == 0
+    scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
+    assert ok.sum() > 200 and (np.abs(D[ok] - Dp[ok]) / scale).max() < D_RTOL
+    gp.close()
+
+
 @pytest.fixture(scope="module")
 def ieee_ctx():
     """Context on the test-only build with -DES_IEEE_DIVISION (lib/libeigensolver_amd_ieee.so): every reciprocal of the
