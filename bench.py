@@ -63,6 +63,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 BYTES_PER_EVAL = 8.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 BYTES_PER_EVAL_WITH_STATUS = BYTES_PER_EVAL + 1.0
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
+LOOP_FP64_PER_POINT_STEP, LOOP_RCP_PER_POINT_STEP = 37, 1   # ISA of shoot_grid_kernel<0,4,256,false,3>: 296 fp64 + 8 rcp per 8 point-steps
 FLOPS_PER_STEP = 2 * 9 + 8 + 26             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step in the scaled-coefficient form without the division by 3 (8 fma, 2 fma-by-2, 6 add = 26)
 
 
@@ -91,6 +92,18 @@ def measured_traffic_per_launch():
         return (f + w) * 1024.0, "profiles/bench_pmc_hbm_latest.json (" + str(d.get("round", "?")) + ")"
     except Exception:
         return None, None
+
+
+def measured_cycles_per_launch():
+    """(GPU cycles, VALU wave-instructions) per launch of the dominant kernel from the committed SQ / GRBM pass
+    (GRBM_GUI_ACTIVE is summed over the 8 XCDs; under counter collection every launch runs alone)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "bench_pmc_hbm_latest.json")))
+        cyc = [v["mean_per_dispatch"] for k, v in d["GRBM_GUI_ACTIVE"].items() if "shoot_grid_kernel" in k][0] / 8.0
+        ins = [v["mean_per_dispatch"] for k, v in d["SQ_INSTS_VALU"].items() if "shoot_grid_kernel" in k][0]
+        return cyc, ins, "profiles/bench_pmc_hbm_latest.json (" + str(d.get("round", "?")) + ")"
+    except Exception:
+        return None, None, None
 
 
 def host_cores():
@@ -463,6 +476,16 @@ def main():
                                             if unshared else None),
                           "flops_per_eval": FLOPS_PER_STEP * nsteps},
         }
+        # issue-slot view of the same kernel (clock-independent): cycles the loop's instruction stream needs at 4 cycles
+        # per fp64 wave-instruction (16 for v_rcp_f64) on 4 SIMDs x 256 CUs, against the cycles a launch takes (PMC)
+        cyc, ins, cyc_src = measured_cycles_per_launch()
+        if cyc and world == 1 and not skip:
+            need = (LOOP_FP64_PER_POINT_STEP * 4 + LOOP_RCP_PER_POINT_STEP * 16) * (launch_evals / 64.0) * nsteps / 1024.0
+            out["valu_issue"] = {"loop_fp64_instructions_per_point_step": LOOP_FP64_PER_POINT_STEP,
+                                 "loop_rcp_per_point_step": LOOP_RCP_PER_POINT_STEP,
+                                 "issue_cycles_needed_per_launch": need, "cycles_per_launch": cyc,
+                                 "frac": need / cyc, "valu_wave_instructions_per_launch": ins, "source": cyc_src,
+                                 "clock_ghz_alone": cyc / (float(np.mean(unshared)) * 1e-3) / 1e9 if unshared else None}
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu
         if share > 1:

@@ -28,6 +28,9 @@ for name in ("fetch", "write", "sq"):
             out[cn] = {k: {"dispatches": len(v), key: sum(v) / len(v)} for k, v in d.items()}
 json.dump(out, open(os.path.join(pr, f"{tag}_bench_pmc.json"), "w"), indent=1)
 hbm = {k: out[k] for k in ("FETCH_SIZE", "WRITE_SIZE") if k in out}
+for k in ("GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"):                       # bench.py's valu_issue: cycles and instructions per grid launch
+    if k in out:
+        hbm[k] = {n: v for n, v in out[k].items() if "shoot_grid_kernel" in n}
 hbm["round"] = tag
 json.dump(hbm, open(os.path.join(pr, "bench_pmc_hbm_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
