@@ -173,7 +173,7 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
         }
 #undef ES_MARCH_STEP
 #pragma unroll
-        for (int p = 0; p < PTS; ++p) adjoint_rescale<FAM>(zp[p], zq[p], nst);
+        for (int p = 0; p < PTS; ++p) adjoint_rescale<FAM>(zp[p], zq[p], nsteps - c0 - nst, nsteps - c0);
       }
       if (STASH) {
 #pragma unroll
@@ -1091,7 +1091,7 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
       const int c0 = ch * es_shoot_shared::CH;
       const int nst = (nsteps - c0 < es_shoot_shared::CH) ? (nsteps - c0) : es_shoot_shared::CH;
       for (int i = 0; i < nst; ++i) c *= 3.0;
-      c = ldexp(c, adjoint_rescale_exp(nst));
+      c = ldexp(c, adjoint_rescale_exp(nsteps - c0 - nst, nsteps - c0));
     }
     S.bc_const = d->bc_const * c;
   }

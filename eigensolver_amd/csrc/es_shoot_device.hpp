@@ -357,7 +357,8 @@ __device__ __forceinline__ void rk4_step_adjoint_scaled0(double& p, double& q, c
 // homogeneous: D depends on z_p / z_q; a non-zero target is multiplied by the same factor, see adjoint_scale), so the
 // marches of that family drop the division by 3: 3 z' = t1 + 2 t2 + t3 - z + A1^T t3 -- 16 instructions per step
 // instead of 18.  z then grows by 3 per step and is brought back by an exact power of two at the end of every LDS
-// chunk: adjoint_rescale(nst) = 2^-floor(nst log2 3) after nst steps.
+// chunk, chosen from the number of steps marched so far so that the accumulated factor 3^s 2^-floor(s log2 3) stays in
+// [1, 2) whatever the node count: adjoint_rescale(s_before, s_after) = 2^-(floor(s_after log2 3) - floor(s_before log2 3)).
 __device__ __forceinline__ void rk4_step_adjoint_scaled0_x3(double& p, double& q, const Coef& B0, const Coef& Bm,
                                                             const Coef& B1) {
   const double tp1 = fma(B0.a21, q, p),   tq1 = fma(B0.a12, p, q);
@@ -373,12 +374,14 @@ __device__ __forceinline__ void rk4_step_adjoint_scaled0_x3(double& p, double& q
 // families whose fp64 marches carry z times a known factor (rk4_step_adjoint_scaled0_x3)
 template <int FAM> constexpr bool fam_unnormalised() { return FAM == FAM_CYL0; }
 
-__host__ __device__ inline int adjoint_rescale_exp(int nst) { return -(int)((double)nst * 1.5849625007211561); }   // -floor(nst log2 3)
+__host__ __device__ inline int adjoint_rescale_exp(int s_before, int s_after) {
+  return (int)((double)s_before * 1.5849625007211561) - (int)((double)s_after * 1.5849625007211561);
+}
 
 template <int FAM>
-__device__ __forceinline__ void adjoint_rescale(double& p, double& q, int nst) {
+__device__ __forceinline__ void adjoint_rescale(double& p, double& q, int s_before, int s_after) {
   if (fam_unnormalised<FAM>()) {
-    const int ex = adjoint_rescale_exp(nst);
+    const int ex = adjoint_rescale_exp(s_before, s_after);
     p = ldexp(p, ex);
     q = ldexp(q, ex);
   }

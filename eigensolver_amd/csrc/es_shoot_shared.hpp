@@ -104,7 +104,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
       adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
       B0 = B1;
     }
-    adjoint_rescale<FAM>(zp, zq, nst);
+    adjoint_rescale<FAM>(zp, zq, nsteps - c0 - nst, nsteps - c0);   // steps marched before / after this chunk
   }
   const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
   finish_point(P, M, X, TRACK ? trk.crossed() : band_crossed(P, k, w), D, rel, st);

@@ -26,7 +26,9 @@
 #include "../../include/eigensolver_amd.h"
 
 #define PORT_CH 128                                     /* es_shoot_shared::CH */
-static int port_rescale_exp(int nst) { return -(int)((double)nst * 1.5849625007211561); }   /* adjoint_rescale_exp */
+static int port_rescale_exp(int s_before, int s_after) {   /* adjoint_rescale_exp: steps marched before / after the chunk */
+  return (int)((double)s_before * 1.5849625007211561) - (int)((double)s_after * 1.5849625007211561);
+}
 #define PI 3.14159265358979323846264338327950288
 #define EULER 0.57721566490153286060651209008240243
 
@@ -164,7 +166,7 @@ port_problem* port_create(const es_shoot_desc* d, const es_profiles* pr) {
     for (int ch = (nsteps + PORT_CH - 1) / PORT_CH - 1; ch >= 0; --ch) {
       const int c0 = ch * PORT_CH, nst = (nsteps - c0 < PORT_CH) ? (nsteps - c0) : PORT_CH;
       for (int i = 0; i < nst; ++i) c *= 3.0;
-      c = ldexp(c, port_rescale_exp(nst));
+      c = ldexp(c, port_rescale_exp(nsteps - c0 - nst, nsteps - c0));
     }
     P->bc_const = d->bc_const * c;
   }
@@ -483,7 +485,7 @@ static int port_eval_core(const port_problem* P, double k, double w, double w_cs
     B0 = B1;
     if (P->family == 0 && j % PORT_CH == 0) {          /* end of an LDS chunk of the HIP march: adjoint_rescale */
       const int nst = (nsteps - j < PORT_CH) ? (nsteps - j) : PORT_CH;
-      const int ex = port_rescale_exp(nst);
+      const int ex = port_rescale_exp(nsteps - j - nst, nsteps - j);
       zp = ldexp(zp, ex); zq = ldexp(zq, ex);
     }
   }
