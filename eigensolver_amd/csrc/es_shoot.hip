@@ -1034,17 +1034,31 @@ extern "C" int es_problem_create(es_context* ctx, const es_shoot_desc* d, const 
         B(C0_E1, i) = 1.0 / (r * rho);
         B(C0_E2, i) = r / rho;
       } else {
-        B(CT_R, i) = r;
-        B(CT_INVR, i) = 1.0 / r;
-        B(CT_RHO, i) = rho;
-        B(CT_S, i) = S;
-        B(CT_Q, i) = q;
-        B(CT_BA, i) = bA;
+        // the k-independent parts of the node entries, in the operation order make_entry used per lane and node
+        const double dm = (double)d->m, dm2 = dm * dm;
+        const double invr = 1.0 / r, invr2 = invr * invr;
+        const double bphr = Bphi / r, vphr = vphi / r;
+        const double Bphi_n = bphr * r, vphi_n = vphr * r;   // as the device formed them from the stored B_phi/r, v_phi/r
+        B(CT_MB, i) = dm * bphr;
         B(CT_BZ, i) = Bz;
-        B(CT_BPHR, i) = Bphi / r;
-        B(CT_VPHR, i) = vphi / r;
+        B(CT_BA, i) = bA;
+        B(CT_MV, i) = dm * vphr;
         B(CT_VZ, i) = vz;
+        B(CT_Q, i) = q;
+        B(CT_E3, i) = rho * S;
+        B(CT_RHO, i) = rho;
+        B(CT_E5, i) = rho * vphi_n * vphi_n * invr;
+        B(CT_E6, i) = 2.0 * Bphi_n * Bphi_n * invr;
+        B(CT_C7, i) = 2.0 * Bphi_n * vphi_n;
+        B(CT_INVR, i) = invr;
+        B(CT_BPHI, i) = Bphi_n;
+        B(CT_E9, i) = rho * vphi_n;
+        B(CT_E10, i) = 2.0 * dm * S * invr2;
+        B(CT_S, i) = S;
+        B(CT_M2R2, i) = dm2 * invr2;
         B(CT_RDC3, i) = pr->rdC3 ? pr->rdC3[i] : 0.0;
+        B(CT_E13, i) = 4.0 * S * invr2;
+        B(CT_R, i) = r;
       }
     }
   } else if (d->geometry == ES_GEOM_SLAB_DENSITY) {

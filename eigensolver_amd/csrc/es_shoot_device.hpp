@@ -57,7 +57,7 @@ template <int FAM> struct FamTraits;
 template <int FAM> constexpr bool fam_has_bands() { return FAM == FAM_CYL0 || FAM == FAM_SLABF || FAM == FAM_SLABD; }
 // SHAPE of A for the adjoint march: 0 off-diagonal (a11 = a22 = 0), 1 full, 2 companion (a11 = 0, a12 = 1)
 template <> struct FamTraits<FAM_CYL0> { static constexpr int NB = 7, NE = 7, SHAPE = 0; static constexpr bool DIAG = false; };
-template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 11, NE = 16, SHAPE = 1; static constexpr bool DIAG = true; };
+template <> struct FamTraits<FAM_CYLT> { static constexpr int NB = 20, NE = 16, SHAPE = 1; static constexpr bool DIAG = true; };
 template <> struct FamTraits<FAM_SLABD> { static constexpr int NB = 3, NE = 5, SHAPE = 0; static constexpr bool DIAG = false; };
 template <> struct FamTraits<FAM_SLABF> { static constexpr int NB = 3, NE = 4, SHAPE = 2; static constexpr bool DIAG = true; };
 
@@ -66,7 +66,10 @@ template <int FAM> constexpr bool fam_scaled() { return FAM == FAM_CYL0; }
 
 // base-field indices
 enum { C0_VZ = 0, C0_BA, C0_Q, C0_A1, C0_B1, C0_E1, C0_E2 };
-enum { CT_R = 0, CT_INVR, CT_RHO, CT_S, CT_Q, CT_BA, CT_BZ, CT_BPHR, CT_VPHR, CT_VZ, CT_RDC3 };
+// twisted cylinder: everything of the node entries that does not depend on k is formed once, on the host, for the
+// problem's m (es_problem_create, operation for operation what make_entry did per lane and node before: same values)
+enum { CT_MB = 0 /* m B_phi/r */, CT_BZ, CT_BA, CT_MV /* m v_phi/r */, CT_VZ, CT_Q, CT_E3 /* rho S */, CT_RHO, CT_E5, CT_E6,
+       CT_C7 /* 2 B_phi v_phi */, CT_INVR, CT_BPHI, CT_E9, CT_E10, CT_S, CT_M2R2 /* m^2/r^2 */, CT_RDC3, CT_E13, CT_R };
 enum { SD_RHO = 0, SD_C2, SD_VA2 };
 enum { SF_U = 0, SF_DU, SF_DDU };
 
@@ -112,28 +115,25 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
     e[6] = -(Bq * (e[2] * e[2]));
     if (SCALED) { e[3] *= s.h2; e[4] *= s.h2; e[5] *= s.h2; e[6] *= s.h2; }
   } else if (FAM == FAM_CYLT) {
-    const double r = b[CT_R], invr = b[CT_INVR], rho = b[CT_RHO], S = b[CT_S];
-    const double Bphi = b[CT_BPHR] * r, vphi = b[CT_VPHR] * r;
-    const double kb = s.m * b[CT_BPHR] + s.k * b[CT_BZ];        // m B_phi/r + k B_z
-    const double wA = s.m * b[CT_BPHR] + s.k * b[CT_BA];        // as written in the reference (CF:581)
+    const double kb = b[CT_MB] + s.k * b[CT_BZ];               // m B_phi/r + k B_z
+    const double wA = b[CT_MB] + s.k * b[CT_BA];               // as written in the reference (CF:581)
     const double wA2 = wA * wA;
-    const double invr2 = invr * invr;
-    e[0] = s.m * b[CT_VPHR] + s.k * b[CT_VZ];   // shift: m v_phi/r + k v_z
+    e[0] = b[CT_MV] + s.k * b[CT_VZ];                          // shift: m v_phi/r + k v_z
     e[1] = wA2;
     e[2] = wA2 * b[CT_Q];
-    e[3] = rho * S;
-    e[4] = rho;
-    e[5] = rho * vphi * vphi * invr;            // q1
-    e[6] = 2.0 * Bphi * Bphi * invr;            // q2
-    e[7] = 2.0 * Bphi * vphi * kb * invr;       // q3
-    e[8] = kb * Bphi;                           // tt1
-    e[9] = rho * vphi;                          // tt2
-    e[10] = 2.0 * s.m * S * invr2;              // c1c
-    e[11] = S * (s.m2 * invr2 + s.k2);          // c2c
-    e[12] = b[CT_RDC3];                         // r d/dr[(B_phi/r)^2 - rho (v_phi/r)^2]
-    e[13] = 4.0 * S * invr2;                    // c3b
-    e[14] = r;
-    e[15] = invr;
+    e[3] = b[CT_E3];                                           // rho S
+    e[4] = b[CT_RHO];
+    e[5] = b[CT_E5];                                           // q1 = rho v_phi^2 / r
+    e[6] = b[CT_E6];                                           // q2 = 2 B_phi^2 / r
+    e[7] = b[CT_C7] * kb * b[CT_INVR];                         // q3 = 2 B_phi v_phi kb / r
+    e[8] = kb * b[CT_BPHI];                                    // tt1
+    e[9] = b[CT_E9];                                           // tt2 = rho v_phi
+    e[10] = b[CT_E10];                                         // c1c = 2 m S / r^2
+    e[11] = b[CT_S] * (b[CT_M2R2] + s.k2);                     // c2c = S (m^2/r^2 + k^2)
+    e[12] = b[CT_RDC3];                                        // r d/dr[(B_phi/r)^2 - rho (v_phi/r)^2]
+    e[13] = b[CT_E13];                                         // c3b = 4 S / r^2
+    e[14] = b[CT_R];
+    e[15] = b[CT_INVR];
   } else if (FAM == FAM_SLABD) {
     const double rho = b[SD_RHO], c2 = b[SD_C2], vA2 = b[SD_VA2];
     const double S = c2 + vA2;
