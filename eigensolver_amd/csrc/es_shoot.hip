@@ -44,14 +44,17 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
                                                           double* __restrict__ Dout, double* __restrict__ relout,
                                                           uint8_t* __restrict__ stout, GridOpts opts) {
   constexpr int NE = FamTraits<FAM>::NE;
-  constexpr int LSTRIDE = 2 * CH + 1;
+  // even row stride and a 16-byte aligned table: the entries of nodes 2j, 2j+1 of every row are one aligned 16-byte pair,
+  // read by ds_read_b128 at an immediate offset from ONE address register (with the odd stride every other row needed
+  // ds_read2_b64 from its own base register: 7 address moves per loop iteration, 2 % of its VALU instructions)
+  constexpr int LSTRIDE = 2 * CH + 2;
   // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
   constexpr bool PAIR = (FAM == FAM_CYL0) && (PTS == 4) && !TRACK;
   // register-capped instantiations (WPE != 0) park the exterior results in LDS during the march instead of letting
   // the compiler spill them to scratch (HBM): 4 doubles per point, lane-contiguous (conflict-free)
   constexpr bool STASH = (WPE != 0);
   __shared__ double xstash[STASH ? 4 * PTS * MAXT : 1];
-  __shared__ double lds[NE * LSTRIDE];
+  __shared__ __attribute__((aligned(16))) double lds[NE * LSTRIDE];
   const int T = blockDim.x;
   const int nsteps = P.n_nodes - 1;
   const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
