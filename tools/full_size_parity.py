@@ -1,6 +1,9 @@
 """GPU box: the WHOLE bench grid (4096 x 4096, BASELINE configs[3]) against the CPU port, point by point -- statuses,
 D, rel -- and the root table of the grid search against the port's.  Writes gpurun_out/full_size_parity.json.
-    python tools/full_size_parity.py [threads]"""
+    python tools/full_size_parity.py [threads]
+    python tools/full_size_parity.py config4 [threads]   -> BASELINE configs[4] (rotational flow, m = 0..10, 1024 x 1024 per order,
+                                                            N = 2000): the fp64 grid and the MIXED search of every order
+                                                            against the port; writes gpurun_out/full_size_parity_config4.json"""
 import json
 import os
 import sys
@@ -14,7 +17,59 @@ import bench  # noqa: E402
 from tests import cases  # noqa: E402
 
 
+def config4(nthreads):
+    import torch
+    from eigensolver_amd import ShootProblem, _lib, equilibrium as q
+    n = 1024
+    k = np.linspace(0.25, 4.0, n)
+    W = 0.7 + (np.arange(n) + 0.5) * ((1.45 - 0.7) / n)
+    kt = torch.as_tensor(k, device="cuda"); Wt = torch.as_tensor(W, device="cuda")
+    ctx = _lib.Context(0)
+    rows = []
+    for m in range(11):
+        eq = q.CylinderRotation(v_twist=0.1, power=1.0, r_axis=0.01 if m == 0 else 0.001)
+        mode = "sausage" if m == 0 else "kink"
+        port = cases.port_problem(eq, mode, m)
+        t0 = time.time()
+        Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=nthreads)
+        rp, cntp = port.find_roots(k, W, Dp, stp, w_mode=1, n_bisect=bench.N_BISECT, tol=bench.TOL_PERCENT, nthreads=nthreads)
+        t_port = time.time() - t0
+        gp = ShootProblem(eq, mode, m=m, ctx=ctx)
+        D, st = gp.eval_grid(kt, Wt)
+        Dg, stg = D.cpu().numpy(), st.cpu().numpy()
+        ok = stp == 0
+        scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
+        err = np.abs(Dg[ok] - Dp[ok]) / scale
+        sd = np.signbit(Dg[ok]) != np.signbit(Dp[ok])
+        roots, cnt, _, stm, stats = gp.find_roots_mixed(kt, Wt, n_bisect=bench.N_BISECT, tol_percent=bench.TOL_PERCENT)
+        g = {a: v.cpu().numpy() for a, v in roots.items()}
+        same = cnt == cntp and np.array_equal(g["row"], rp["row"]) and np.array_equal(g["flag"], rp["flag"])
+        dw = np.abs(g["w"] - rp["w"]) / np.abs(rp["w"]) if same else np.array([np.inf])
+        row = {"m": m, "port_seconds": t_port, "statuses_identical": bool(np.array_equal(stg, stp)),
+               "mixed_statuses_identical": bool(np.array_equal(stm.cpu().numpy(), stp)),
+               "status_histogram": np.bincount(stp.ravel(), minlength=4)[:4].tolist(),
+               "max_abs_dD_over_scale": float(err.max()), "sign_differences": int(sd.sum()),
+               "max_abs_D_over_scale_at_sign_differences": float((np.abs(Dp[ok][sd]) / scale[sd]).max()) if sd.any() else 0.0,
+               "brackets": [int(cnt), int(cntp)], "mixed_bracket_rows_and_flags_identical": bool(same),
+               "accepted_roots": int((rp["flag"] == 1).sum()), "max_rel_root_difference": float(dw.max()),
+               "fp64_reevaluations": [int(x) for x in stats]}
+        print(json.dumps(row), flush=True)
+        rows.append(row)
+        gp.close()
+    out = {"orders": rows, "all_statuses_identical": all(r["statuses_identical"] and r["mixed_statuses_identical"] for r in rows),
+           "all_bracket_tables_identical": all(r["mixed_bracket_rows_and_flags_identical"] for r in rows),
+           "max_abs_dD_over_scale": max(r["max_abs_dD_over_scale"] for r in rows),
+           "max_rel_root_difference": max(r["max_rel_root_difference"] for r in rows),
+           "sign_differences": sum(r["sign_differences"] for r in rows),
+           "brackets": sum(r["brackets"][0] for r in rows), "accepted_roots": sum(r["accepted_roots"] for r in rows)}
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "full_size_parity_config4.json"), "w"), indent=1)
+    print(json.dumps({a: v for a, v in out.items() if a != "orders"}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "config4":
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        return config4(int(sys.argv[2]) if len(sys.argv) > 2 else bench.host_cores())
     nthreads = int(sys.argv[1]) if len(sys.argv) > 1 else bench.host_cores()
     eq = bench.workload_equilibrium()
     k, W = bench.workload_grid()
