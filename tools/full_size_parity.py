@@ -1,6 +1,8 @@
 """GPU box: the WHOLE bench grid (4096 x 4096, BASELINE configs[3]) against the CPU port, point by point -- statuses,
 D, rel -- and the root table of the grid search against the port's.  Writes gpurun_out/full_size_parity.json.
     python tools/full_size_parity.py [threads]
+    python tools/full_size_parity.py configs12 [threads] -> BASELINE configs[1] and configs[2], fp64 grid + grid search; writes
+                                                            gpurun_out/full_size_parity_configs12.json
     python tools/full_size_parity.py config4 [threads]   -> BASELINE configs[4] (rotational flow, m = 0..10, 1024 x 1024 per order,
                                                             N = 2000): the fp64 grid and the MIXED search of every order
                                                             against the port; writes gpurun_out/full_size_parity_config4.json"""
@@ -66,7 +68,70 @@ def config4(nthreads):
     print(json.dumps({a: v for a, v in out.items() if a != "orders"}, indent=1))
 
 
+def compare(gp, port, k, W, n_bisect, tol, nthreads, label):
+    """fp64 grid and grid search of one problem, GPU against the port, every point."""
+    import torch
+    t0 = time.time()
+    Dp, relp, stp = port.eval_grid(k, W, w_mode=1, nthreads=nthreads)
+    rp, cntp = port.find_roots(k, W, Dp, stp, w_mode=1, n_bisect=n_bisect, tol=tol, nthreads=nthreads)
+    t_port = time.time() - t0
+    kt = torch.as_tensor(k, device="cuda"); Wt = torch.as_tensor(W, device="cuda")
+    D, st = gp.eval_grid(kt, Wt)
+    roots, cnt = gp.find_roots(kt, Wt, D, st, n_bisect=n_bisect, tol_percent=tol)
+    Dg, stg = D.cpu().numpy(), st.cpu().numpy()
+    ok = stp == 0
+    scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
+    err = np.abs(Dg[ok] - Dp[ok]) / scale
+    sd = np.signbit(Dg[ok]) != np.signbit(Dp[ok])
+    g = {a: v.cpu().numpy() for a, v in roots.items()}
+    same = cnt == cntp and np.array_equal(g["row"], rp["row"]) and np.array_equal(g["flag"], rp["flag"])
+    dw = np.abs(g["w"] - rp["w"]) / np.abs(rp["w"]) if (same and cnt) else np.array([0.0 if same else np.inf])
+    row = {"problem": label, "points": int(Dp.size), "port_seconds": t_port, "statuses_identical": bool(np.array_equal(stg, stp)),
+           "status_histogram": np.bincount(stp.ravel(), minlength=4)[:4].tolist(),
+           "max_abs_dD_over_scale": float(err.max()) if ok.any() else 0.0, "sign_differences": int(sd.sum()),
+           "max_abs_D_over_scale_at_sign_differences": float((np.abs(Dp[ok][sd]) / scale[sd]).max()) if sd.any() else 0.0,
+           "brackets": [int(cnt), int(cntp)], "bracket_rows_and_flags_identical": bool(same),
+           "accepted_roots": int((rp["flag"] == 1).sum()), "max_rel_root_difference": float(dw.max())}
+    print(json.dumps(row), flush=True)
+    return row
+
+
+def configs12(nthreads):
+    """BASELINE configs[1] (slab / non-uniform flow, 1024 x 1024, both modes) and configs[2] (cylinder / non-uniform density,
+    m = 0..4, 4096 k-points x 384 omega) as tests/test_configs_gpu.py defines them, at full size."""
+    from eigensolver_amd import ShootProblem, _lib, equilibrium as q
+    ctx = _lib.Context(0)
+    rows = []
+    eq = q.SlabFlow(U_i0=0.35, width=1.5)
+    k = np.linspace(0.05, 3.5, 1024)
+    W = 1.4 + (np.arange(1024) + 0.5) * (2.45 - 1.4) / 1024
+    for mode in ("sausage", "kink"):
+        gp = ShootProblem(eq, mode, ctx=ctx)
+        rows.append(compare(gp, cases.port_problem(eq, mode), k, W, 30, 1e-3, nthreads, f"configs[1] slab flow {mode}"))
+        gp.close()
+    eq = q.CylinderDensity(width=0.95)
+    k = np.linspace(0.01, 4.5, 4096)
+    W = 2.05 + (np.arange(384) + 0.5) * (4.95 - 2.05) / 384
+    for m in range(5):
+        mode = "sausage" if m == 0 else "kink"
+        gp = ShootProblem(eq, mode, m=m, ctx=ctx)
+        rows.append(compare(gp, cases.port_problem(eq, mode, m), k, W, 30, 1e-3, nthreads, f"configs[2] cylinder density m={m}"))
+        gp.close()
+    out = {"problems": rows, "all_statuses_identical": all(r["statuses_identical"] for r in rows),
+           "all_bracket_tables_identical": all(r["bracket_rows_and_flags_identical"] for r in rows),
+           "points": sum(r["points"] for r in rows), "sign_differences": sum(r["sign_differences"] for r in rows),
+           "max_abs_D_over_scale_at_sign_differences": max(r["max_abs_D_over_scale_at_sign_differences"] for r in rows),
+           "max_abs_dD_over_scale": max(r["max_abs_dD_over_scale"] for r in rows),
+           "max_rel_root_difference": max(r["max_rel_root_difference"] for r in rows),
+           "brackets": sum(r["brackets"][0] for r in rows), "accepted_roots": sum(r["accepted_roots"] for r in rows)}
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "full_size_parity_configs12.json"), "w"), indent=1)
+    print(json.dumps({a: v for a, v in out.items() if a != "problems"}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "configs12":
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        return configs12(int(sys.argv[2]) if len(sys.argv) > 2 else bench.host_cores())
     if len(sys.argv) > 1 and sys.argv[1] == "config4":
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         return config4(int(sys.argv[2]) if len(sys.argv) > 2 else bench.host_cores())
