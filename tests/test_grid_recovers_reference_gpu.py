@@ -1,5 +1,5 @@
 """The grid path (es_shoot_eval_grid + es_shoot_find_roots: the bench's path) against the roots the REFERENCE found in
-its own driver sweeps (tests/golden/roots_*.json, executed in the build container), for the calls whose reference run
+its own driver sweeps and traced worker calls (tests/golden/roots_*.json, trace_*.json, executed in the build container), for the calls whose reference run
 was clean (classified "identical" by tests/test_reference_agreement.py: no silent fsolve failure, no singular point).
 The reference reports two kinds of "roots":
   * refined ones -- a sign change between two samples of its frequency band, narrowed by locate_* until the mismatch is
@@ -22,12 +22,13 @@ AGREEMENT = json.load(open(os.path.join(G, "agreement_table.json")))
 NW = 1536
 
 
-@pytest.mark.parametrize("name", refcases.rootset_names())
-def test_grid_search_finds_the_reference_roots(es_ctx, name):
+@pytest.mark.parametrize("kind,name", [("roots", n) for n in refcases.rootset_names()] +
+                         [("trace", n) for n in refcases.trace_names()])
+def test_grid_search_finds_the_reference_roots(es_ctx, kind, name):
     key, factory = refcases.solver_factories()[name]
     solver = factory(es_ctx)
-    calls = refcases.load_calls("roots", name)
-    cats = AGREEMENT[f"roots:{name}"]
+    calls = refcases.load_calls(kind, name)
+    cats = AGREEMENT[f"{kind}:{name}"]
     n_refined = n_found = n_sampled = n_sampled_ok = 0
     missing = []
     for mode in sorted({c["fn"] for c in calls}):
@@ -64,7 +65,7 @@ def test_grid_search_finds_the_reference_roots(es_ctx, name):
             good = (sts.cpu().numpy() == 0) & (rels.cpu().numpy() < tol)
             n_sampled += len(sampled)
             n_sampled_ok += int(good.sum())
-    print(f"{name}: refined reference roots recovered by the grid search {n_found} / {n_refined}; sampled ones accepted by the GPU "
+    print(f"{kind}:{name}: refined reference roots recovered by the grid search {n_found} / {n_refined}; sampled ones accepted by the GPU "
           f"evaluation {n_sampled_ok} / {n_sampled}; missing: {missing[:4]}")
     assert n_found == n_refined, (name, missing[:6])
     assert n_sampled_ok == n_sampled, name
