@@ -355,7 +355,7 @@ __device__ __forceinline__ void rk4_step_adjoint_scaled0(double& p, double& q, c
 
 // The determinant needs the row z only up to a common factor (the far-end condition of the untwisted cylinder is
 // homogeneous: D depends on z_p / z_q; a non-zero target is multiplied by the same factor, see adjoint_scale), so the
-// marches of that family drop the division by 3: 3 z' = t1 + 2 t2 + t3 - z + A1^T t3 -- 16 instructions per step
+// marches of that family drop the division by 3: 3 z' = t1 + 2 t2 + t3 - z + A1^T t3 -- 14 instructions per step
 // instead of 18.  z then grows by 3 per step and is brought back by an exact power of two at the end of every LDS
 // chunk, chosen from the number of steps marched so far so that the accumulated factor 3^s 2^-floor(s log2 3) stays in
 // [1, 2) whatever the node count: adjoint_rescale(s_before, s_after) = 2^-(floor(s_after log2 3) - floor(s_before log2 3)).
@@ -365,8 +365,9 @@ __device__ __forceinline__ void rk4_step_adjoint_scaled0_x3(double& p, double& q
   const double tp2 = fma(Bm.a21, tq1, p), tq2 = fma(Bm.a12, tp1, q);
   const double am2 = Bm.a21 + Bm.a21,     bm2 = Bm.a12 + Bm.a12;
   const double tp3 = fma(am2, tq2, p),    tq3 = fma(bm2, tp2, q);
-  const double sp = fma(2.0, tp2, tp1 + tp3) - p;
-  const double sq = fma(2.0, tq2, tq1 + tq3) - q;
+  // t1 + 2 t2 + (t3 - z) with t3 - z = 2 Am^T t2 taken as the product it is: two fmas per component instead of add, fma, sub
+  const double sp = fma(am2, tq2, fma(2.0, tp2, tp1));
+  const double sq = fma(bm2, tp2, fma(2.0, tq2, tq1));
   p = fma(B1.a21, tq3, sp);
   q = fma(B1.a12, tp3, sq);
 }

@@ -357,8 +357,9 @@ static void rk4_adjoint_scaled0(double* p, double* q, const coef* B0, const coef
   const double tp2 = fma(Bm->a21, tq1, *p), tq2 = fma(Bm->a12, tp1, *q);
   const double am2 = Bm->a21 + Bm->a21, bm2 = Bm->a12 + Bm->a12;
   const double tp3 = fma(am2, tq2, *p), tq3 = fma(bm2, tp2, *q);
-  const double sp = fma(2.0, tp2, tp1 + tp3) - *p;
-  const double sq = fma(2.0, tq2, tq1 + tq3) - *q;
+  /* t1 + 2 t2 + (t3 - z), t3 - z = 2 Am^T t2 taken as the product (as the HIP step) */
+  const double sp = fma(am2, tq2, fma(2.0, tp2, tp1));
+  const double sq = fma(bm2, tp2, fma(2.0, tq2, tq1));
   /* rk4_step_adjoint_scaled0_x3: no division by 3 (D depends on z_p / z_q only); the factor 3 per step is taken back by
      an exact power of two at the end of every chunk of PORT_CH steps, as in the HIP kernels */
   *p = fma(B1->a21, tq3, sp);
