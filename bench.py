@@ -49,6 +49,8 @@ def refine_plan(n_brackets):
     """(sections, rounds, distinct determinant evaluations per bracket) of es_shoot_find_roots for N_BISECT: 17-section
     with 16 lanes per bracket up to 32768 brackets (4 rounds: 17^4 >= 2^16), 9-section with 8 lanes beyond (6 rounds)."""
     sections = 17 if n_brackets <= 32768 else 9
+    if os.environ.get("ES_REFINE_SECTIONS") in ("5", "9", "17"):    # tuning aid of the library, see DESIGN.md
+        sections = int(os.environ["ES_REFINE_SECTIONS"])
     rounds, span = 0, 1.0
     while span < 2.0 ** N_BISECT:
         span *= sections

@@ -962,7 +962,11 @@ template <int FAM>
 int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, double* d_lo, double* d_hi, int n,
                   int n_bisect, double tol) {
   // (LANES+1)-section rounds equivalent to n_bisect halvings: (LANES+1)^R >= 2^n_bisect
-  const int sections = refine_sections(n);
+  int sections = refine_sections(n);
+  if (const char* ev = getenv("ES_REFINE_SECTIONS")) {            // tuning aid, honoured by the port as well: 5, 9 or 17
+    const int v = atoi(ev);
+    if (v == 5 || v == 9 || v == 17) sections = v;
+  }
   int rounds = 0;
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
   // section rounds with LANES lanes per bracket, then the polish steps with one lane per bracket (d_lo / d_hi carry D at
@@ -971,8 +975,11 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   if (sections == 17)
     hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
                        dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
-  else
+  else if (sections == 9)
     hipLaunchKernelGGL((refine_kernel<FAM, 8>), dim3((n + 8 * REFINE_WAVES - 1) / (8 * REFINE_WAVES)),
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
+  else
+    hipLaunchKernelGGL((refine_kernel<FAM, 4>), dim3((n + 16 * REFINE_WAVES - 1) / (16 * REFINE_WAVES)),
                        dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
   if (np < 0) {
