@@ -65,7 +65,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 BYTES_PER_EVAL = 8.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 BYTES_PER_EVAL_WITH_STATUS = BYTES_PER_EVAL + 1.0
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-LOOP_FP64_PER_POINT_STEP, LOOP_RCP_PER_POINT_STEP = 35, 1   # ISA of shoot_grid_kernel<0,4,256,false,3>: 272 fp64 + 8 rcp (+ 1 move) per 8 point-steps
+LOOP_FP64_PER_POINT_STEP, LOOP_RCP_PER_POINT_STEP = 34, 1   # ISA of shoot_grid_kernel<0,4,256,false,3>: 272 fp64 (96 fma, 88 fmac, 56 mul, 32 add) + 8 rcp (+ 1 move) per 8 point-steps
 FLOPS_PER_STEP = 2 * 9 + 8 + 26             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step in the scaled-coefficient form without the division by 3 (12 fma, 2 add = 26)
 
 
