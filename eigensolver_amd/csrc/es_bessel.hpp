@@ -36,6 +36,42 @@ ES_HD double qdiv(double a, double b) {
 #endif
 }
 
+// Reciprocals of the x-independent divisors of the loops below -- 1/k (series) and 1/i, 1/a_i with a_i = -(i - 1/2)^2
+// (CF2) -- from constant memory on the device: the loop index is wave-uniform, so they arrive by scalar loads, and a
+// multiply replaces a reciprocal sequence (v_rcp_f64 is quarter rate: 16 issue cycles + 4 instructions each).  1/k is the
+// correctly rounded quotient the host computes; beyond the table, and in the ES_IEEE_DIVISION build, the quotient itself.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ES_IEEE_DIVISION)
+#define ES_BESSEL_TABLES 1
+#define ES_R(k) (1.0 / (double)(k))
+#define ES_R8(k) ES_R(k), ES_R((k) + 1), ES_R((k) + 2), ES_R((k) + 3), ES_R((k) + 4), ES_R((k) + 5), ES_R((k) + 6), ES_R((k) + 7)
+#define ES_A(i) (1.0 / (-(((double)(i)) - 0.5) * (((double)(i)) - 0.5)))
+#define ES_A8(i) ES_A(i), ES_A((i) + 1), ES_A((i) + 2), ES_A((i) + 3), ES_A((i) + 4), ES_A((i) + 5), ES_A((i) + 6), ES_A((i) + 7)
+constexpr int kRcpTable = 64;
+static __constant__ double kRcpInt[kRcpTable] = {0.0, ES_R(1), ES_R(2), ES_R(3), ES_R(4), ES_R(5), ES_R(6), ES_R(7), ES_R8(8), ES_R8(16),
+                                                 ES_R8(24), ES_R8(32), ES_R8(40), ES_R8(48), ES_R8(56)};
+static __constant__ double kRcpCF2a[kRcpTable] = {0.0, ES_A(1), ES_A(2), ES_A(3), ES_A(4), ES_A(5), ES_A(6), ES_A(7), ES_A8(8), ES_A8(16),
+                                                  ES_A8(24), ES_A8(32), ES_A8(40), ES_A8(48), ES_A8(56)};
+#undef ES_R
+#undef ES_R8
+#undef ES_A
+#undef ES_A8
+#endif
+
+// a / k for a small positive integer k (wave-uniform)
+ES_HD double qdiv_int(double a, int k) {
+#if defined(ES_BESSEL_TABLES)
+  if (k < kRcpTable) return a * kRcpInt[k];
+#endif
+  return qdiv(a, (double)k);
+}
+// a / a_i, a_i = -(i - 1/2)^2 (the second CF2 coefficient sequence; `ai` is its value, used beyond the table)
+ES_HD double qdiv_cf2a(double a, int i, double ai) {
+#if defined(ES_BESSEL_TABLES)
+  if (i < kRcpTable) return a * kRcpCF2a[i];
+#endif
+  return qdiv(a, ai);
+}
+
 constexpr double kEulerGamma = 0.57721566490153286060651209008240243;
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
@@ -49,8 +85,7 @@ ES_HD void ke01(double x, double& k0, double& k1) {
     double term0 = 1.0, i0 = 1.0, s0 = 0.0, hk = 0.0;
     double term1 = 1.0, i1 = 1.0, s1 = 1.0;      // k = 0: H_0 + H_1 = 1
     for (int k = 1; k < 40; ++k) {
-      const double kk = (double)k;
-      const double rk = qdiv(1.0, kk), rk1 = qdiv(1.0, kk + 1.0);
+      const double rk = qdiv_int(1.0, k), rk1 = qdiv_int(1.0, k + 1);
       term0 = term0 * t * (rk * rk);
       hk += rk;
       i0 += term0;
@@ -72,8 +107,8 @@ ES_HD void ke01(double x, double& k0, double& k1) {
     double s = 1.0 + q * delh;
     for (int i = 2; i < 500; ++i) {
       a -= 2.0 * (double)(i - 1);
-      c = qdiv(-a * c, (double)i);
-      const double qnew = qdiv(q1 - b * q2, a);
+      c = qdiv_int(-a * c, i);
+      const double qnew = qdiv_cf2a(q1 - b * q2, i, a);
       q1 = q2;
       q2 = qnew;
       q += c * qnew;
