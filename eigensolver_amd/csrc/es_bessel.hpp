@@ -4,7 +4,7 @@
 //
 // Exponentially scaled forms are used throughout:  Ke_n(x) = e^x K_n(x),  Ie_n(x) = e^-x I_n(x).
 //   * K_0, K_1:  x <= 2  ascending series (A&S 9.6.12-13 form with harmonic numbers);
-//                x >  2  Steed's continued fraction CF2 (Temme), as in the classic bessik algorithm;
+//                x >  2  Chebyshev series of sqrt(x) e^x K_{0,1}(x) in 4/x - 1 (Steed's CF2 until round 2);
 //                then the upward recurrence K_{n+1} = K_{n-1} + (2n/x) K_n (stable).
 //   * I_n, I_{n+1}: ascending power series (all terms positive, no cancellation); only called for x < ~50
 //                where the I-admixture of the far-field initial values is not below rounding.
@@ -75,6 +75,35 @@ ES_HD double qdiv_cf2a(double a, int i, double ai) {
 constexpr double kEulerGamma = 0.57721566490153286060651209008240243;
 constexpr double kPi = 3.14159265358979323846264338327950288;
 
+// sqrt(x) e^x K_0(x) and sqrt(x) e^x K_1(x) on x >= 2 as Chebyshev series in y = 4/x - 1 (25 terms: the 26th is below 2e-18;
+// coefficients by interpolation at 96 Chebyshev nodes in 50-digit arithmetic, mpmath).  Evaluated by Clenshaw's recurrence
+// the pair is within 2.8e-16 of the true values on [2, 700] (tests/test_hostmath.py against scipy.special.kve) at about
+// 110 instructions, where Steed's CF2 needed 10 ... 40 iterations of 25 instructions and a reciprocal each.
+#define ES_CHEB_K0 { \
+    1.2201515410329777, -0.0314481013119645, 0.0015698838857300533, -0.00012849549581627802, \
+    1.39498137188765e-05, -1.8317555227191195e-06, 2.766813639445015e-07, -4.660489897687948e-08, \
+    8.574034017414225e-09, -1.6975345093890614e-09, 3.5773972814003283e-10, -7.957489244477396e-11, \
+    1.8559491149549264e-11, -4.514597883374519e-12, 1.1403405882073441e-12, -2.9800969231481784e-13, \
+    8.032890775068375e-14, -2.2275133267462965e-14, 6.340076476276646e-15, -1.848593377920907e-15, \
+    5.5120559994043335e-16, -1.6782311257549006e-16, 5.2103917776435543e-17, -1.6475805939842632e-17, \
+    5.3004337711773354e-18 }
+#define ES_CHEB_K1 { \
+    1.3603130952422213, 0.10392373657681724, -0.002857816859622779, 0.00019521551847135162, \
+    -1.936197974166083e-05, 2.406484947837217e-06, -3.5019606030878126e-07, 5.7410841254500495e-08, \
+    -1.0345762465678097e-08, 2.0150497551970347e-09, -4.1903547593419254e-10, 9.218315187605315e-11, \
+    -2.129967838427791e-11, 5.139639673482343e-12, -1.2891739609498229e-12, 3.348419666052243e-13, \
+    -8.976705182010146e-14, 2.4771544242195988e-14, -7.0198370892147685e-15, 2.038703166239861e-15, \
+    -6.057047270643018e-16, 1.8380935752430455e-16, -5.689462849193648e-17, 1.7940510478863572e-17, \
+    -5.7567444820733025e-18 }
+constexpr int kChebN = 25;
+#if defined(__HIP_DEVICE_COMPILE__)
+static __constant__ double kChebK0[kChebN] = ES_CHEB_K0;     // wave-uniform index: scalar loads
+static __constant__ double kChebK1[kChebN] = ES_CHEB_K1;
+#else
+static const double kChebK0[kChebN] = ES_CHEB_K0;
+static const double kChebK1[kChebN] = ES_CHEB_K1;
+#endif
+
 // scaled K_0, K_1 (e^x K)
 ES_HD void ke01(double x, double& k0, double& k1) {
   if (x <= 2.0) {
@@ -99,30 +128,19 @@ ES_HD void ke01(double x, double& k0, double& k1) {
     k0 = ex * (-lg * i0 + s0);
     k1 = ex * (qdiv(1.0, x) + lg * (0.5 * x) * i1 - 0.25 * x * s1);
   } else {
-    // CF2, order mu = 0
-    double b = 2.0 * (1.0 + x), d = qdiv(1.0, b), h = d, delh = d;
-    double q1 = 0.0, q2 = 1.0;
-    const double a1 = 0.25;
-    double q = a1, c = a1, a = -a1;
-    double s = 1.0 + q * delh;
-    for (int i = 2; i < 500; ++i) {
-      a -= 2.0 * (double)(i - 1);
-      c = qdiv_int(-a * c, i);
-      const double qnew = qdiv_cf2a(q1 - b * q2, i, a);
-      q1 = q2;
-      q2 = qnew;
-      q += c * qnew;
-      b += 2.0;
-      d = qdiv(1.0, b + a * d);
-      delh = (b * d - 1.0) * delh;
-      h += delh;
-      const double dels = q * delh;
-      s += dels;
-      if (fabs(dels) < 1e-17 * fabs(s)) break;
+    // Chebyshev series of sqrt(x) e^x K_{0,1}(x) in y = 4/x - 1, Clenshaw: b_j = 2 y b_{j+1} - b_{j+2} + c_j
+    const double y = qdiv(4.0, x) - 1.0, y2 = y + y;
+    double p1 = 0.0, p2 = 0.0, q1 = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int j = kChebN - 1; j >= 1; --j) {
+      const double pn = fma(y2, p1, kChebK0[j] - p2);
+      const double qn = fma(y2, q1, kChebK1[j] - q2);
+      p2 = p1; p1 = pn;
+      q2 = q1; q1 = qn;
     }
-    h = a1 * h;
-    k0 = qdiv(sqrt(qdiv(kPi, 2.0 * x)), s);
-    k1 = qdiv(k0 * (x + 0.5 - h), x);
+    const double rs = qdiv(1.0, sqrt(x));
+    k0 = fma(y, p1, kChebK0[0] - p2) * rs;
+    k1 = fma(y, q1, kChebK1[0] - q2) * rs;
   }
 }
 

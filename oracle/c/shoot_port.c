@@ -29,6 +29,7 @@
 static int port_rescale_exp(int s_before, int s_after) {   /* adjoint_rescale_exp: steps marched before / after the chunk */
   return (int)((double)s_before * 1.5849625007211561) - (int)((double)s_after * 1.5849625007211561);
 }
+#define PORT_CHEB_N 25
 #define PI 3.14159265358979323846264338327950288
 #define EULER 0.57721566490153286060651209008240243
 
@@ -52,26 +53,34 @@ static void ke01(double x, double* k0, double* k1) {
     *k0 = ex * (-lg * i0 + s0);
     *k1 = ex * (1.0 / x + lg * (0.5 * x) * i1 - 0.25 * x * s1);
   } else {
-    double b = 2.0 * (1.0 + x), d = 1.0 / b, h = d, delh = d, q1 = 0.0, q2 = 1.0;
-    const double a1 = 0.25;
-    double q = a1, c = a1, a = -a1, s = 1.0 + q * delh;
-    for (int i = 2; i < 500; ++i) {
-      a -= 2.0 * (double)(i - 1);
-      c = -a * c / (double)i;
-      double qnew = (q1 - b * q2) / a;
-      q1 = q2; q2 = qnew;
-      q += c * qnew;
-      b += 2.0;
-      d = 1.0 / (b + a * d);
-      delh = (b * d - 1.0) * delh;
-      h += delh;
-      double dels = q * delh;
-      s += dels;
-      if (fabs(dels) < 1e-17 * fabs(s)) break;
+    /* Chebyshev series of sqrt(x) e^x K_{0,1}(x) in y = 4/x - 1 (the tables of csrc/es_bessel.hpp), Clenshaw's recurrence in
+       the operation order of the HIP code (whose qdiv is the IEEE quotient in the ES_IEEE_DIVISION build) */
+    static const double c0[PORT_CHEB_N] = {
+    1.2201515410329777, -0.0314481013119645, 0.0015698838857300533, -0.00012849549581627802, 
+    1.39498137188765e-05, -1.8317555227191195e-06, 2.766813639445015e-07, -4.660489897687948e-08, 
+    8.574034017414225e-09, -1.6975345093890614e-09, 3.5773972814003283e-10, -7.957489244477396e-11, 
+    1.8559491149549264e-11, -4.514597883374519e-12, 1.1403405882073441e-12, -2.9800969231481784e-13, 
+    8.032890775068375e-14, -2.2275133267462965e-14, 6.340076476276646e-15, -1.848593377920907e-15, 
+    5.5120559994043335e-16, -1.6782311257549006e-16, 5.2103917776435543e-17, -1.6475805939842632e-17, 
+    5.3004337711773354e-18 };
+    static const double c1[PORT_CHEB_N] = {
+    1.3603130952422213, 0.10392373657681724, -0.002857816859622779, 0.00019521551847135162, 
+    -1.936197974166083e-05, 2.406484947837217e-06, -3.5019606030878126e-07, 5.7410841254500495e-08, 
+    -1.0345762465678097e-08, 2.0150497551970347e-09, -4.1903547593419254e-10, 9.218315187605315e-11, 
+    -2.129967838427791e-11, 5.139639673482343e-12, -1.2891739609498229e-12, 3.348419666052243e-13, 
+    -8.976705182010146e-14, 2.4771544242195988e-14, -7.0198370892147685e-15, 2.038703166239861e-15, 
+    -6.057047270643018e-16, 1.8380935752430455e-16, -5.689462849193648e-17, 1.7940510478863572e-17, 
+    -5.7567444820733025e-18 };
+    const double y = 4.0 / x - 1.0, y2 = y + y;
+    double p1 = 0.0, p2 = 0.0, q1 = 0.0, q2 = 0.0;
+    for (int j = PORT_CHEB_N - 1; j >= 1; --j) {
+      const double pn = fma(y2, p1, c0[j] - p2), qn = fma(y2, q1, c1[j] - q2);
+      p2 = p1; p1 = pn;
+      q2 = q1; q1 = qn;
     }
-    h = a1 * h;
-    *k0 = sqrt(PI / (2.0 * x)) / s;
-    *k1 = *k0 * (x + 0.5 - h) / x;
+    const double rs = 1.0 / sqrt(x);
+    *k0 = fma(y, p1, c0[0] - p2) * rs;
+    *k1 = fma(y, q1, c1[0] - q2) * rs;
   }
 }
 static void ke_pair(int n, double x, double* kn, double* kn1) {
