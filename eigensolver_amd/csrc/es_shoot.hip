@@ -375,12 +375,15 @@ constexpr int REFINE_WAVES = 4;
 
 // WPE = 3 (<= 168 VGPRs: 165 for the untwisted cylinder, no spill; two grid waves of 168 and one refinement wave share a
 // SIMD's 512 registers) except for the twisted family, which needs 234 and would spill (WPE = 2).
-template <int FAM, int LANES, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+// CHR > 0: the node entries of a bracket are formed once per chunk of CHR steps by the wave into its own LDS table and
+// shared by the LANES lanes of the bracket (shoot_point_wavegroup); CHR = 0: every lane forms its own (shoot_point).
+template <int FAM, int LANES, int CHR = 0, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, int n, int n_rounds,   // d_lo / d_hi alias table columns
                                                     int n_polish, double tol_percent) {
-  ES_POINT_LDS(FAM);
   constexpr int GROUPS = 64 / LANES;
+  constexpr int WTBL = GROUPS * (2 * (CHR > 0 ? CHR : 1) + 1) * FamTraits<FAM>::NE;      // doubles per wave
+  __shared__ double es_point_lds[CHR > 0 ? REFINE_WAVES * WTBL : FamTraits<FAM>::NB * (2 * es_shoot_shared::CH + 1)];
   const int lane = threadIdx.x & 63;
   const int g = lane / LANES, j = lane % LANES;
   const int i = (blockIdx.x * REFINE_WAVES + ((int)threadIdx.x >> 6)) * GROUPS + g;
@@ -412,7 +415,8 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, in
     } else {
       x = lo + (hi - lo) * 0.5;                        // n_polish = 0: report the bracket mid-point
     }
-    shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
+    if (CHR > 0) shoot_point_wavegroup<FAM, (CHR > 0 ? CHR : 1), GROUPS>(P, k, x, D, rel, st, es_point_lds + ((int)threadIdx.x >> 6) * WTBL);
+    else shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     if (section) {
       const bool diff = (D * flo < 0.0);               // NaN products compare false, as in the reference
       const unsigned long long bal = __ballot(diff);
@@ -972,7 +976,16 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   // section rounds with LANES lanes per bracket, then the polish steps with one lane per bracket (d_lo / d_hi carry D at
   // the ends of the narrowed bracket from one kernel to the other)
   const int np = (ES_REFINE_POLISH > 0 && rounds > 0) ? -1 : ES_REFINE_POLISH;
-  if (sections == 17)
+  // 17-section of the untwisted cylinder with np < 0 (sections only): node entries shared inside the wave, 32 steps per
+  // chunk (14.6 KB of LDS per wave).  Measured, same box: one-stream step 22.19 against 22.55 ms, pipelined 21.47 against
+  // 21.74 ms, the 512-row tile unchanged.  The twisted family (16 entries per node: 17 KB per wave at 16 steps per chunk,
+  // one workgroup per CU) lost 7 % on configs[4] and keeps per-lane entries.
+  constexpr int CHR = (FAM == FAM_CYL0) ? 32 : 0;
+  const bool shared_entries = CHR > 0 && np < 0 && !getenv("ES_REFINE_PRIVATE_ENTRIES");
+  if (sections == 17 && shared_entries)
+    hipLaunchKernelGGL((refine_kernel<FAM, 16, CHR>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
+                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
+  else if (sections == 17)
     hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
                        dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
   else if (sections == 9)

@@ -110,6 +110,81 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
   finish_point(P, M, X, TRACK ? trk.crossed() : band_crossed(P, k, w), D, rel, st);
 }
 
+// The 64 lanes of a WAVE fall into NG groups of 64 / NG lanes with the SAME k each (the section points of one bracket):
+// the node entries -- what of a one-point march depends on (node, k) only, 40 % of its instructions -- are formed once
+// per group and node by the wave itself into its own LDS table `tbl` ([NG][2 CHR + 1][NE] doubles per chunk of CHR
+// steps) and read back by the lanes of the group (one address per group: broadcast).  No workgroup barrier: a wave only
+// reads what it wrote (LDS operations of a wave complete in order; the wave barrier keeps the compiler from moving
+// them across).  The k of every group is fetched by shuffles up front.  The entries are
+// make_entry's of the per-lane form and the arithmetic after them is shoot_point_impl's: results bit-identical.
+template <int FAM, bool TRACK, int CHR, int NG>
+__device__ __forceinline__ void shoot_point_wavegroup_impl(const ShootDev& P, double k, double w, double& D, double& rel,
+                                                           uint8_t& st, double* __restrict__ tbl) {
+  constexpr int NE = FamTraits<FAM>::NE;
+  constexpr int NB = FamTraits<FAM>::NB;
+  constexpr int NODES = 2 * CHR + 1;
+  constexpr int GL = 64 / NG;                          // lanes per group
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / GL;
+  const KScal s = make_kscal(P, k);
+  const int nsteps = P.n_nodes - 1;
+  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
+  SignTrack trk;
+  double e[NE], e2[NE];
+  const ExteriorLite X = exterior_lite(P, k, w, w);
+  Coef B0;
+  double zp = 0.0, zq = 0.0;
+  const double* mine = tbl + (size_t)grp * NODES * NE;
+  double kgs[NG];                                      // the k of every group, fetched while all lanes are active
+#pragma unroll
+  for (int g2 = 0; g2 < NG; ++g2) kgs[g2] = __shfl(k, g2 * GL);
+  const int nchunks = (nsteps + CHR - 1) / CHR;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int c0 = c * CHR;
+    const int nst = (nsteps - c0 < CHR) ? (nsteps - c0) : CHR;
+    const int nn = 2 * nst + 1;
+    __builtin_amdgcn_wave_barrier();                   // previous chunk consumed by every lane of this wave
+    for (int idx = lane; idx < NG * nn; idx += 64) {
+      const int g2 = idx / nn, i = idx - g2 * nn;
+      double kg = kgs[0];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) kg = (g2 == q) ? kgs[q] : kg;
+      const KScal sg = make_kscal(P, kg);
+      double b[NB], eg[NE];
+#pragma unroll
+      for (int f = 0; f < NB; ++f) b[f] = P.base[(size_t)f * P.npts + 2 * c0 + i];
+      make_entry<FAM, fam_scaled<FAM>()>(b, sg, eg);
+#pragma unroll
+      for (int f = 0; f < NE; ++f) tbl[((size_t)g2 * NODES + i) * NE + f] = eg[f];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (c == nchunks - 1) {                            // last node: start vector of the march
+#pragma unroll
+      for (int f = 0; f < NE; ++f) e[f] = mine[2 * nst * NE + f];
+      coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
+      adjoint_start(P, B0, zp, zq);
+    }
+    for (int j = nst - 1; j >= 0; --j) {
+      Coef Bm, B1;
+#pragma unroll
+      for (int f = 0; f < NE; ++f) { e[f] = mine[(2 * j + 1) * NE + f]; e2[f] = mine[2 * j * NE + f]; }
+      coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
+      adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+      B0 = B1;
+    }
+    adjoint_rescale<FAM>(zp, zq, nsteps - c0 - nst, nsteps - c0);
+  }
+  const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
+  finish_point(P, M, X, TRACK ? trk.crossed() : band_crossed(P, k, w), D, rel, st);
+}
+
+template <int FAM, int CHR, int NG>
+__device__ __forceinline__ void shoot_point_wavegroup(const ShootDev& P, double k, double w, double& D, double& rel,
+                                                      uint8_t& st, double* __restrict__ tbl) {
+  if (fam_has_bands<FAM>() && P.use_bands) shoot_point_wavegroup_impl<FAM, !fam_has_bands<FAM>(), CHR, NG>(P, k, w, D, rel, st, tbl);
+  else shoot_point_wavegroup_impl<FAM, true, CHR, NG>(P, k, w, D, rel, st, tbl);
+}
+
 template <int FAM>
 __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
                                             double& rel, uint8_t& st, double* __restrict__ sb) {
