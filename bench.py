@@ -24,6 +24,11 @@ tiling of round 1: rank r solves azimuthal order m = r + 1 on the full grid.
 With --gpus N > 1 and no WORLD_SIZE in the environment this process only starts the N ranks
 (python -m torch.distributed.run ...) as a child process and never touches the GPU itself.
 
+--workload config1 | config2 | config4: the other GPU configurations of BASELINE.json (never the headline), same JSON
+contract: slab / non-uniform flow 1024 x 1024 both modes; cylinder / non-uniform density m = 0..4, 4096 k; cylinder /
+rotational flow m = 0..10 with fp32 screening + fp64 refinement.  Their units (modes / azimuthal orders) run on one HIP
+stream each; N > 1: every rank owns the k-rows r, r + N, ... of EVERY unit (equal point counts), one all-gather per step.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -45,10 +50,10 @@ N_BISECT = 16                                 # bracket narrowed by >= 2^16, the
 REFINE_POLISH = 2                             # -> |d omega/omega| ~ 1e-16
 
 
-def refine_plan(n_brackets):
+def refine_plan(n_brackets=0):
     """(sections, rounds, distinct determinant evaluations per bracket) of es_shoot_find_roots for N_BISECT: 17-section
-    with 16 lanes per bracket up to 32768 brackets (4 rounds: 17^4 >= 2^16), 9-section with 8 lanes beyond (6 rounds)."""
-    sections = 17 if n_brackets <= 32768 else 9
+    with 16 lanes per bracket (4 rounds: 17^4 >= 2^16), whatever the bracket count (the rule must not depend on the tiling)."""
+    sections = 17
     if os.environ.get("ES_REFINE_SECTIONS") in ("5", "9", "17"):    # tuning aid of the library, see DESIGN.md
         sections = int(os.environ["ES_REFINE_SECTIONS"])
     rounds, span = 0, 1.0
@@ -57,7 +62,7 @@ def refine_plan(n_brackets):
         rounds += 1
     return sections, rounds, (sections - 1) * rounds + REFINE_POLISH
 TOL_PERCENT = 1e-3
-EXCHANGE_CAP = 1 << 15                        # records per rank in the fixed-capacity all-gather (6 doubles each)
+# the capacity of the fixed-size all-gather is sized from the data during warm-up (distributed.exchange_capacity)
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 # algorithmic traffic per det-eval of the grid kernel: 8 B of D written + amortised inputs; the kernel
@@ -65,7 +70,6 @@ FP64_VALU_PEAK_TFLOPS = 78.6                  # fp64 vector peak (spec)
 BYTES_PER_EVAL = 8.0 + 16.0 * (1.0 / NW + 1.0 / NK)
 BYTES_PER_EVAL_WITH_STATUS = BYTES_PER_EVAL + 1.0
 # fp64 operations per det-eval of the grid kernel (FMA = 2, division = 1), see DESIGN.md "kernel K3"
-LOOP_FP64_PER_POINT_STEP, LOOP_RCP_PER_POINT_STEP = 34, 1   # ISA of shoot_grid_kernel<0,4,256,false,3>: 272 fp64 (96 fma, 88 fmac, 56 mul, 32 add) + 8 rcp (+ 1 move) per 8 point-steps
 FLOPS_PER_STEP = 2 * 9 + 8 + 26             # 2 coefficient sets (1 add, 3 fma, 2 mul each) + shared reciprocal (1 div, 3 mul, 2 fma) + one adjoint RK4 step in the scaled-coefficient form without the division by 3 (12 fma, 2 add = 26)
 
 
@@ -81,31 +85,93 @@ def workload_grid():
     return k, W
 
 
-def measured_traffic_per_launch():
+def _pmc_file(workload):
+    """Committed rocprofv3 PMC summary of THIS workload's bench command (tools/profile_bench.sh <tag> <workload> +
+    tools/summarize_profiles.py): profiles/pmc_latest_<workload>.json; the headline also under its round-1 name."""
+    for name in (f"pmc_latest_{workload}.json",) + (("bench_pmc_hbm_latest.json",) if workload == "config3" else ()):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), "profiles/" + name
+            except Exception:
+                pass
+    return None, None
+
+
+def _grid_entry(d, counter, key):
+    """Per-dispatch mean of `counter` for the grid-march kernel (fp64 or fp32 screening) in a PMC summary."""
+    best = None
+    for k, v in (d.get(counter) or {}).items():
+        if "shoot_grid" in k and (best is None or v.get("dispatches", 0) > best.get("dispatches", 0)):
+            best = v
+    return None if best is None else best.get(key)
+
+
+def measured_traffic_per_launch(workload="config3"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same command, profiles/README.md) and where they come from."""
-    path = os.path.join(ROOT, "profiles", "bench_pmc_hbm_latest.json")
-    try:
-        d = json.load(open(path))
-        f = [v["mean_KB_per_dispatch"] for k, v in d["FETCH_SIZE"].items() if "shoot_grid_kernel" in k][0]
-        w = [v["mean_KB_per_dispatch"] for k, v in d["WRITE_SIZE"].items() if "shoot_grid_kernel" in k][0]
-        # gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads (x2 correction of the guide);
-        # the reads of this kernel are 8-B scalar/LDS-staging loads of a 56 KB table, left uncorrected
-        return (f + w) * 1024.0, "profiles/bench_pmc_hbm_latest.json (" + str(d.get("round", "?")) + ")"
-    except Exception:
+    d, src = _pmc_file(workload)
+    if d is None:
         return None, None
+    f = _grid_entry(d, "FETCH_SIZE", "mean_KB_per_dispatch")
+    w = _grid_entry(d, "WRITE_SIZE", "mean_KB_per_dispatch")
+    if f is None or w is None:
+        return None, None
+    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads (x2 correction of the guide);
+    # the reads of this kernel are 8-B scalar/LDS-staging loads of a small L2-resident table, left uncorrected
+    return (f + w) * 1024.0, src + " (" + str(d.get("round", "?")) + ")"
 
 
-def measured_cycles_per_launch():
+def measured_cycles_per_launch(workload="config3"):
     """(GPU cycles, VALU wave-instructions) per launch of the dominant kernel from the committed SQ / GRBM pass
     (GRBM_GUI_ACTIVE is summed over the 8 XCDs; under counter collection every launch runs alone)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "bench_pmc_hbm_latest.json")))
-        cyc = [v["mean_per_dispatch"] for k, v in d["GRBM_GUI_ACTIVE"].items() if "shoot_grid_kernel" in k][0] / 8.0
-        ins = [v["mean_per_dispatch"] for k, v in d["SQ_INSTS_VALU"].items() if "shoot_grid_kernel" in k][0]
-        return cyc, ins, "profiles/bench_pmc_hbm_latest.json (" + str(d.get("round", "?")) + ")"
-    except Exception:
+    d, src = _pmc_file(workload)
+    if d is None:
         return None, None, None
+    cyc = _grid_entry(d, "GRBM_GUI_ACTIVE", "mean_per_dispatch")
+    ins = _grid_entry(d, "SQ_INSTS_VALU", "mean_per_dispatch")
+    if cyc is None:
+        return None, None, None
+    return cyc / 8.0, ins, src + " (" + str(d.get("round", "?")) + ")"
+
+
+def loop_model(kernel):
+    """Instruction counts of the march loop of `kernel` (spelled as rocprofv3 prints it, blanks removed) from the
+    disassembly of the shipped code object: profiles/isa_loop_counts.json, written by tools/isa_loop_count.py --write and
+    held to the built library by tests/test_codeobj.py."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "isa_loop_counts.json")))
+        return t.get(kernel)
+    except Exception:
+        return None
+
+
+def valu_views(kernel, launch_evals, nsteps, grid_ms, unshared_ms, workload, pmc_ok=True):
+    """`valu_fp64` (executed fp64 flops of the loop's own instruction stream against the fp64 vector peak) and `valu_issue`
+    (issue cycles that stream needs against the cycles a launch takes) of one launch of `kernel`."""
+    m = loop_model(kernel)
+    if m is None:
+        return None, None
+    p = m["per_point_step"]
+    fp64 = p.get("fp64_fma", 0.0) * 2.0 + p.get("fp64", 0.0) + p.get("rcp_f64", 0.0)
+    f32 = (p.get("packed_f32_fma", 0.0) * 4.0 + p.get("packed_f32", 0.0) * 2.0 + p.get("f32_fma", 0.0) * 2.0 + p.get("f32", 0.0)
+           + p.get("rcp_f32", 0.0))
+    flops = fp64 + f32
+    tfl = launch_evals * flops * nsteps / (grid_ms * 1e-3) / 1e12
+    fp64_view = {"achieved": tfl, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / FP64_VALU_PEAK_TFLOPS,
+                 "frac_unshared": (tfl * grid_ms / unshared_ms / FP64_VALU_PEAK_TFLOPS) if unshared_ms else None,
+                 "flops_per_point_step": flops, "flops_per_eval": flops * nsteps,
+                 "note": "flops EXECUTED by the march loop of " + kernel + " (fma = 2; ISA count, profiles/isa_loop_counts.json)"
+                         + ("; fp32 screening march: priced against the fp64 vector peak only for comparison" if f32 else "")}
+    issue = None
+    cyc, ins, src = measured_cycles_per_launch(workload) if pmc_ok else (None, None, None)
+    need = m["issue_cycles_per_wave_point_step"] * (launch_evals / 64.0) * nsteps / 1024.0
+    issue = {"kernel": kernel, "loop_instructions_per_point_step": {k_: round(v, 3) for k_, v in p.items()},
+             "issue_cycles_per_wave_point_step": m["issue_cycles_per_wave_point_step"],
+             "issue_cycles_needed_per_launch": need, "cycles_per_launch": cyc,
+             "frac": (need / cyc) if cyc else None, "valu_wave_instructions_per_launch": ins, "source": src,
+             "frac_at_2p1_ghz_unshared": (need / (unshared_ms * 1e-3 * 2.1e9)) if unshared_ms else None}
+    return fp64_view, issue
 
 
 def host_cores():
@@ -136,14 +202,14 @@ def host_cores():
     return n
 
 
-def cpu_baselines(eq, m, k_np, W_np, target_seconds=10.0):
+def cpu_baselines(eq, m, k_np, W_np, target_seconds=10.0, mode="kink", numpy_leg=True):
     """Two CPU legs on ALL host cores, each on a bounded sample of k-rows of the same grid (run before this process
     touches the GPU): (1) the oracle's C port (same algorithm as the HIP kernel, plain C + OpenMP);
     (2) the vectorised NumPy restatement (oracle/grid_numpy.py), one process per k-tile."""
     from oracle.port import PortProblem
     from oracle import grid_numpy
     from eigensolver_amd import shooting as s
-    d, p = s.make_desc(eq, "kink", m)
+    d, p = s.make_desc(eq, mode, m)
     desc = {f[0]: getattr(d, f[0]) for f in d._fields_}
     port = PortProblem(desc, p)
     cores = host_cores()
@@ -163,6 +229,8 @@ def cpu_baselines(eq, m, k_np, W_np, target_seconds=10.0):
            "kind": "port",
            "sample": f"{len(rows)} of {len(k_np)} k-rows x {len(W_np)} omega (same grid, C port oracle/c/shoot_port.c, "
                      f"OpenMP {cores} threads, {dt:.1f} s)"}
+    if not numpy_leg:
+        return out, None
     # NumPy leg: calibrate on one row in-process, then one process per k-tile
     prof = {k_: np.asarray(v) for k_, v in p.items()}
     g = grid_numpy.CylinderGrid(desc, prof)
@@ -210,10 +278,12 @@ def main():
     ap.add_argument("--no-extra-mode", action="store_true",
                     help="do not measure the other continuum mode after the timed region (profiling runs: keeps the "
                          "per-kernel counters of one mode apart)")
-    ap.add_argument("--workload", choices=("config3", "config4"), default="config3",
-                    help="config3 (default, the headline): BASELINE.json configs[3]; config4: configs[4], Cylinder / "
-                         "rotational flow, m = 0..10, fp32 bracket + fp64 refine (a second, never the headline, line)")
-    ap.add_argument("--precision", choices=("mixed", "f64"), default="mixed", help="config4 only")
+    ap.add_argument("--workload", choices=("config1", "config2", "config3", "config4"), default="config3",
+                    help="config3 (default, the headline): BASELINE.json configs[3]; config1: Slab / non-uniform flow, "
+                         "1024x1024, both modes; config2: Cylinder / non-uniform density, m = 0..4, 4096 k; config4: Cylinder / "
+                         "rotational flow, m = 0..10, fp32 bracket + fp64 refine (second lines, never the headline)")
+    ap.add_argument("--precision", choices=("mixed", "f64"), default=None,
+                    help="config4: mixed (default: fp32 screening + fp64 refinement) or f64; config1 / config2 are f64")
     ap.add_argument("--share-of", type=int, default=1,
                     help="N = 1 only, a projection aid and never the judged line: this process computes what rank 0 of a "
                          "--gpus E strong-scaling run computes (k-rows 0, E, 2E, ... and the packing of its exchange "
@@ -222,8 +292,8 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_children(a))
-    if a.workload == "config4":
-        return main_config4(a)
+    if a.workload != "config3":
+        return main_units(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -263,28 +333,43 @@ def main():
     k = torch.as_tensor(k_np[rows_np], dtype=torch.float64, device=dev)
     W = torch.as_tensor(W_np, dtype=torch.float64, device=dev)
     nk_local = int(k.numel())
-    # one lane = (stream, library context, problem, root table); --streams 1: the current stream, everything inline
+    # one lane = (stream, library context, problem, root table, device count); --streams 1: the current stream, inline
     n_lanes = max(1, a.streams)
     lanes = []
     for j in range(n_lanes):
         stream = torch.cuda.current_stream(dev) if n_lanes == 1 else torch.cuda.Stream(device=dev)
         cx = _lib.Context(local_rank, stream=stream)
         pr = ShootProblem(eq, "kink", m=m, ctx=cx)
-        with torch.cuda.stream(stream):
-            tb = pr.alloc_root_table(1 << 18)
-        lanes.append((stream, cx, pr, tb))
+        lanes.append([stream, cx, pr, None, None])
     ctx, prob = lanes[0][1], lanes[0][2]
     torch.cuda.synchronize()
 
     skip = bool(a.skip_continuum)
+    # sizes from the data, once, before anything is timed: the bracket count of this rank's tile (synchronous call), the
+    # table capacity (next power of two >= 2 x count: the asynchronous refinement launches are sized for it) and the
+    # capacity of the fixed-size exchange (one all_reduce(MAX) of the counts; round 2 sent 32768 records per rank for ~820)
+    with torch.cuda.stream(lanes[0][0]):
+        D0, st0 = prob.eval_grid(k, W, skip_continuum=skip)
+        _, nbr0 = prob.find_roots(k, W, D0, st0, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, capacity=1 << 18)
+        del D0, st0
+    table_cap = 1024
+    while table_cap < 2 * nbr0:
+        table_cap *= 2
+    exchange_cap = D.exchange_capacity(nbr0) if (world > 1 or share > 1) else 0
+    for lane in lanes:
+        with torch.cuda.stream(lane[0]):
+            lane[3] = lane[2].alloc_root_table(table_cap)
+            lane[4] = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     import threading
     grid_lock = threading.Lock()
     grid_tail = [None]                             # event after the most recent grid launch of any lane
 
     def compute(j, ev=None):
-        """One pass of the hot path over the rank's tile on lane j; returns with the refinement and the send buffer of the
-        exchange enqueued (`done` marks their completion on the lane's stream)."""
-        stream, cx, pr, tb = lanes[j]
+        """One pass of the hot path over the rank's tile on lane j, everything enqueued and NOTHING read back: grid, bracket
+        flags + scan + emit, refinement with the count in device memory (es_shoot_find_roots_async), send buffer of the
+        exchange; `done` marks their completion on the lane's stream."""
+        stream, cx, pr, tb, cnt = lanes[j]
         with torch.cuda.stream(stream):
             # grid launches of different lanes run one after the other (each has the whole chip, and the events below
             # time one launch); what overlaps with the NEXT step's grid is this step's bracket search and refinement
@@ -299,11 +384,11 @@ def main():
                 tail = torch.cuda.Event()
                 tail.record(stream)
                 grid_tail[0] = tail
-            roots, nbr = pr.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=tb)
-            send = D.pack_fixed(roots, nbr, m, rows_t, EXCHANGE_CAP, ctx=cx) if (world > 1 or share > 1) else None
+            roots = pr.find_roots_async(k, W, D_, st, tb, cnt, n_bisect=N_BISECT, tol_percent=TOL_PERCENT)
+            send = D.pack_fixed(roots, cnt, m, rows_t, exchange_cap, ctx=cx) if exchange_cap else None
             done = torch.cuda.Event()
             done.record(stream)
-        return roots, nbr, send, st, done
+        return roots, cnt, send, st, done
 
     def exchange(send, done):
         # the one exchange of the path: a single all-gather, issued by the main thread in step order on every rank
@@ -313,9 +398,9 @@ def main():
         return D.gather_fixed(send, world)
 
     def step(ev=None):
-        roots, nbr, send, st, done = compute(0, ev)
+        roots, cnt, send, st, done = compute(0, ev)
         buf = exchange(send, done) if world > 1 else None
-        return roots, nbr, buf, st
+        return roots, cnt, buf, st
 
     import queue
     from concurrent.futures import ThreadPoolExecutor
@@ -333,10 +418,11 @@ def main():
     for _ in range(a.warmup):
         for j in range(n_lanes):
             e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            _, _, send_w, _, done_w = compute(j, e)
+            _, cnt_w, send_w, _, done_w = compute(j, e)
             if world > 1:
                 exchange(send_w, done_w)            # also brings the communicator up before the timed region
             torch.cuda.synchronize()
+            assert int(cnt_w.item()) <= table_cap, (int(cnt_w.item()), table_cap)
     # the dominant kernel alone on a busy chip: grid launches back to back on one stream, the first one not counted (a
     # launch that follows idle time runs up to 13 % slower while the clocks ramp: tools/probe/time_small_launches.py)
     alone = []
@@ -357,16 +443,20 @@ def main():
     t0 = time.perf_counter()
     if pool is None:
         for i in range(a.steps):
-            roots, nbr, buf, st = step(events[i])
+            roots, cnt, buf, st = step(events[i])
     else:
         futs = [pool.submit(pipelined, events[i]) for i in range(a.steps)]
         for f in futs:
-            roots, nbr, send, st, done = f.result()
+            roots, cnt, send, st, done = f.result()
             buf = exchange(send, done) if world > 1 else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    nbr = int(cnt.item())                            # the count of the last step, read after the timed region
+    if nbr > table_cap:
+        raise SystemExit(f"bracket count {nbr} exceeds the table capacity {table_cap} sized during warm-up")
+    roots = {key: v[:nbr].clone() for key, v in roots.items()}     # the lane's table is reused by the steps below
 
     # the other mode of the grid evaluation, a few steps outside the timed region (N = 1 only): reported, never `value`
     other = None
@@ -378,11 +468,12 @@ def main():
         t1 = time.perf_counter()
         n_other = max(3, min(10, a.steps))
         for _ in range(n_other):
-            r_o, nbr_o, _, st_o = step()
+            r_o, cnt_o, _, st_o = step()
         torch.cuda.synchronize()
         dt_o = (time.perf_counter() - t1) / n_other
+        nbr_o = int(cnt_o.item())
         n_eval_o = int((st_o != 3).sum()) if skip else nk_local * NW
-        other = {"ms_per_step": dt_o * 1e3, "roots_per_s": int((r_o["flag"] == 1).sum()) / dt_o,
+        other = {"ms_per_step": dt_o * 1e3, "roots_per_s": int((r_o["flag"][:nbr_o] == 1).sum()) / dt_o,
                  "grid_points_evaluated_per_step": n_eval_o, "brackets_per_step": nbr_o,
                  "det_evals_per_s": (n_eval_o + nbr_o * refine_plan(nbr_o)[2]) / dt_o, "steps": n_other}
         skip = not skip
@@ -424,7 +515,7 @@ def main():
         achieved = launch_evals * BYTES_PER_EVAL / (grid_ms * 1e-3) / 1e9
         nsteps = eq.n_nodes - 1
         tflops = launch_evals * FLOPS_PER_STEP * nsteps / (grid_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic_per_launch()
+        traffic, traffic_src = measured_traffic_per_launch("config3")
         if world > 1:
             traffic, traffic_src = None, None            # the committed PMC passes are N = 1 launches
         tot = float(hist.sum().item())
@@ -479,15 +570,16 @@ def main():
                           "flops_per_eval": FLOPS_PER_STEP * nsteps},
         }
         # issue-slot view of the same kernel (clock-independent): cycles the loop's instruction stream needs at 4 cycles
-        # per fp64 wave-instruction (16 for v_rcp_f64) on 4 SIMDs x 256 CUs, against the cycles a launch takes (PMC)
-        cyc, ins, cyc_src = measured_cycles_per_launch()
-        if cyc and world == 1 and not skip:
-            need = (LOOP_FP64_PER_POINT_STEP * 4 + LOOP_RCP_PER_POINT_STEP * 16) * (launch_evals / 64.0) * nsteps / 1024.0
-            out["valu_issue"] = {"loop_fp64_instructions_per_point_step": LOOP_FP64_PER_POINT_STEP,
-                                 "loop_rcp_per_point_step": LOOP_RCP_PER_POINT_STEP,
-                                 "issue_cycles_needed_per_launch": need, "cycles_per_launch": cyc,
-                                 "frac": need / cyc, "valu_wave_instructions_per_launch": ins, "source": cyc_src,
-                                 "clock_ghz_alone": cyc / (float(np.mean(unshared)) * 1e-3) / 1e9 if unshared else None}
+        # per fp64 wave-instruction (16 for v_rcp_f64) on 4 SIMDs x 256 CUs -- counted in the disassembly of the shipped
+        # code object (profiles/isa_loop_counts.json) -- against the cycles a launch takes (PMC)
+        kernel = prob.grid_kernel_name(NW)
+        out["roofline"]["kernel"] = kernel
+        _, issue = valu_views(kernel, launch_evals, nsteps, grid_ms, float(np.mean(unshared)) if unshared else None,
+                              "config3", pmc_ok=(world == 1 and not skip))
+        if issue is not None:
+            out["valu_issue"] = issue
+        out["config"]["exchange_capacity_records"] = exchange_cap
+        out["config"]["root_table_capacity"] = table_cap
         if cpu is not None:
             out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu
         if share > 1:
@@ -501,19 +593,64 @@ def main():
         dist.destroy_process_group()
 
 
-def main_config4(a):
-    """BASELINE.json configs[4]: Cylinder / rotational flow (v_phi = 0.1 r, photospheric constants of
-    Twisted_photospheric_*.py), azimuthal orders m = 0..10, 1024 x 1024 (k, omega) grid per order, N = 2000 interior
-    nodes.  One step = all orders owned by the rank: fp32 screening march + fp64 re-evaluation of the unsure points
-    and of both ends of every bracket + fp64 refinement (es_shoot_find_roots_mixed), or with --precision f64 the fp64
-    path (es_shoot_eval_grid + es_shoot_find_roots) -- the two give bit-identical root tables
-    (tests/test_mixed_gpu.py).  N > 1: the orders are dealt round-robin to the ranks, one all-gather of the root
-    tables per step."""
-    import torch
-    import torch.distributed as dist
+def workload_units(name):
+    """The units (one problem + one (k, omega) grid each) of BASELINE.json configs[1], [2], [4]; the grids are those of
+    tests/test_configs_gpu.py and tools/full_size_parity.py.  Returns (description, n_bisect-independent list of
+    (label, unit id, equilibrium, mode, m, k, W))."""
+    from eigensolver_amd import equilibrium as q
+    if name == "config1":
+        # SF-G (flow_multiprocessor_coronal.py:409-480 workers, :758-821 driver): both modes of the Gaussian flow slab
+        eq = q.SlabFlow(U_i0=0.35, width=1.5)
+        k = np.linspace(0.05, 3.5, 1024)
+        W = 1.4 + (np.arange(1024, dtype=np.float64) + 0.5) * (2.45 - 1.4) / 1024
+        units = [("sausage", 0, eq, "sausage", None, k, W), ("kink", 1, eq, "kink", None, k, W)]
+        desc = ("Slab / non-uniform (Gaussian) flow, coronal, sausage + kink, 1024x1024 (k,omega) grid per mode, fp64 "
+                "(BASELINE.json configs[1]); NOT the headline")
+    elif name == "config2":
+        # CD-C (Density_cylinder.py:546 / :847 workers, :1126-1183 driver): azimuthal orders 0..4 on 4096 wavenumbers
+        eq = q.CylinderDensity(width=0.95)
+        k = np.linspace(0.01, 4.5, 4096)
+        W = 2.05 + (np.arange(384, dtype=np.float64) + 0.5) * (4.95 - 2.05) / 384
+        units = [(f"m={m}", m, eq, "sausage" if m == 0 else "kink", m, k, W) for m in range(5)]
+        desc = ("Cylinder / non-uniform (Gaussian) density, coronal, m = 0..4, 4096 k x 384 omega per order, fp64 "
+                "(BASELINE.json configs[2]); NOT the headline")
+    elif name == "config4":
+        # CR-KF (Twisted_photospheric_nonlinear_flow_kink_fast.py:454-734): rotational flow, orders 0..10
+        k = np.linspace(0.25, 4.0, 1024)
+        W = 0.7 + (np.arange(1024, dtype=np.float64) + 0.5) * ((1.45 - 0.7) / 1024)
+        units = [(f"m={m}", m, q.CylinderRotation(v_twist=0.1, power=1.0, r_axis=0.01 if m == 0 else 0.001),
+                  "sausage" if m == 0 else "kink", m, k, W) for m in range(11)]
+        desc = ("Cylinder / rotational flow (v_phi = 0.1 r), photospheric, m = 0..10, 1024x1024 (k,omega) grid per order, "
+                "N = 2000 nodes (BASELINE.json configs[4]); NOT the headline")
+    else:
+        raise ValueError(name)
+    return desc, units
+
+
+def main_units(a):
+    """BASELINE.json configs[1], [2], [4] under the same contract as the headline.  One step = every unit (mode /
+    azimuthal order) of the workload once: grid march + bracket search + refinement, fp64 (configs[1], [2]) or fp32
+    screening march + fp64 re-evaluation of the unsure points and of both bracket ends + fp64 refinement (configs[4],
+    es_shoot_find_roots_mixed; --precision f64 runs the fp64 path, bit-identical tables: tests/test_mixed_gpu.py).
+    Every unit has its own HIP stream (library context) and host thread: the units are independent problems, and the
+    latency-bound refinement launches of one overlap the grid march of another.  N > 1: rank r owns the k-rows r, r + N,
+    ... of EVERY unit -- equal point counts on every rank (round 2 dealt whole orders round-robin: 2,2,2,1,1,1,1,1 for
+    11 orders on 8 ranks) -- and one all-gather per step carries all units' fixed-capacity tables (capacities sized from
+    the data during warm-up)."""
+    desc, units = workload_units(a.workload)
+    mixed = a.workload == "config4" and a.precision != "f64"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only, before the GPU is initialised
+        u0 = units[len(units) // 2]
+        cpu = cpu_baselines(u0[2], u0[4], u0[5], u0[6], mode=u0[3], numpy_leg=False)[0]
+        cpu["sample"] = f"unit {u0[0]}: " + cpu["sample"]
+    import torch
+    import torch.distributed as dist
     backend = os.environ.get("ES_BENCH_BACKEND", "nccl")
     if os.environ.get("ES_BENCH_SHARE_GPU") == "1":
         local_rank = 0
@@ -524,88 +661,199 @@ def main_config4(a):
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend)
-    from eigensolver_amd import ShootProblem, _lib, equilibrium as q
+    from eigensolver_amd import ShootProblem, _lib
     from eigensolver_amd import distributed as D
-    dev = torch.device(f"cuda:{local_rank}")
-    ctx = _lib.Context(local_rank)
-    n = 1024
-    k = torch.linspace(0.25, 4.0, n, dtype=torch.float64, device=dev)
-    W = 0.7 + (torch.arange(n, dtype=torch.float64, device=dev) + 0.5) * ((1.45 - 0.7) / n)
-    orders = D.tile_modes(list(range(11)), rank, world)
-    # one library context = one HIP stream per azimuthal order, each driven by its own host thread (ctypes releases the
-    # GIL): the orders are independent problems and the refinement / re-evaluation kernels of ONE order cannot fill the
-    # chip (a few thousand brackets -> about one wave per SIMD), so their launches overlap across streams
     from concurrent.futures import ThreadPoolExecutor
+    dev = torch.device(f"cuda:{local_rank}")
+    share = a.share_of if (world == 1 and a.share_of > 1) else 1
     work = []
-    for m in orders:
-        eq = q.CylinderRotation(v_twist=0.1, power=1.0, r_axis=0.01 if m == 0 else 0.001)
+    for label, uid, eq, mode, m, k_np, W_np in units:
+        rows_np = D.tile_rows(len(k_np), rank, world * share, strided=True)
         stream = torch.cuda.Stream(device=dev)
         cx = _lib.Context(local_rank, stream=stream)
-        prob = ShootProblem(eq, "sausage" if m == 0 else "kink", m=m, ctx=cx)
-        with torch.cuda.stream(stream):
-            table = prob.alloc_root_table(1 << 15)
-        work.append((m, prob, stream, table))
-    pool = ThreadPoolExecutor(max_workers=max(1, len(work)))
-    rows_t = torch.arange(n, device=dev)
-    mixed = a.precision == "mixed"
+        cx.grid_timer(True)
+        prob = ShootProblem(eq, mode, m=m, ctx=cx)
+        work.append({"label": label, "uid": uid, "eq": eq, "prob": prob, "stream": stream, "ctx": cx,
+                     "k": torch.as_tensor(k_np[rows_np], dtype=torch.float64, device=dev),
+                     "W": torch.as_tensor(W_np, dtype=torch.float64, device=dev),
+                     "rows": torch.as_tensor(rows_np, device=dev), "nk": len(rows_np), "nw": len(W_np)})
+    pool = ThreadPoolExecutor(max_workers=len(work))
     torch.cuda.synchronize()
 
-    def one_order(item):
-        m, prob, stream, table = item
+    def sizing(item):
+        """Bracket count of the unit's tile (synchronous fp64 call, once, untimed) -> table and exchange capacities."""
+        with torch.cuda.stream(item["stream"]):
+            D_, st = item["prob"].eval_grid(item["k"], item["W"])
+            _, nbr = item["prob"].find_roots(item["k"], item["W"], D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT,
+                                             capacity=1 << 17)
+            hist = torch.bincount(st.reshape(-1).to(torch.int64), minlength=4)[:4].cpu().numpy()
+        return nbr, hist
+
+    sized = list(pool.map(sizing, work))
+    for item, (nbr0, hist) in zip(work, sized):
+        cap = 1024
+        while cap < 2 * nbr0:
+            cap *= 2
+        item["xcap"] = D.exchange_capacity(nbr0) if (world > 1 or share > 1) else 0
+        item["hist"] = hist
+        with torch.cuda.stream(item["stream"]):
+            item["table"] = item["prob"].alloc_root_table(cap)
+            item["cnt"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        item["cap"] = cap
+        item["ctx"].grid_time()                       # forget the sizing launches
+
+    def one_unit(item):
+        prob, stream = item["prob"], item["stream"]
         with torch.cuda.stream(stream):
             if mixed:
-                roots, nbr, _, _, stats = prob.find_roots_mixed(k, W, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
-                nre = stats[0] + stats[1]
+                roots, nbr, _, _, stats = prob.find_roots_mixed(item["k"], item["W"], n_bisect=N_BISECT, tol_percent=TOL_PERCENT,
+                                                                table=item["table"])
+                item["nre"] = stats[0] + stats[1]
+                item["count"] = count = nbr
+                full = item["table"][0]
             else:
-                D_, st = prob.eval_grid(k, W)
-                roots, nbr = prob.find_roots(k, W, D_, st, n_bisect=N_BISECT, tol_percent=TOL_PERCENT, table=table)
-                nre = 0
-            nacc = int((roots["flag"] == 1).sum())
-            buf = D.pack_fixed(roots, nbr, m, rows_t, 1 << 13, ctx=prob.ctx) if world > 1 else None
-            stream.synchronize()
-        return nbr, nacc, nre, buf
+                D_, st = prob.eval_grid(item["k"], item["W"])
+                full = prob.find_roots_async(item["k"], item["W"], D_, st, item["table"], item["cnt"], n_bisect=N_BISECT,
+                                             tol_percent=TOL_PERCENT)
+                item["nre"] = 0
+                count = item["cnt"]
+            send = D.pack_fixed(full, count, item["uid"], item["rows"], item["xcap"], ctx=item["ctx"]) if item["xcap"] else None
+            done = torch.cuda.Event()
+            done.record(stream)
+        return send, done
 
     def step():
-        res = list(pool.map(one_order, work))
-        if world > 1:                                  # one all-gather per step (ranks own 1 or 2 orders: pad to 2)
-            bufs = [r[3] for r in res]
-            while len(bufs) < 2:
-                bufs.append(torch.zeros(((1 << 13) + 1, D.N_FIELDS), dtype=torch.float64, device=dev))
-            D.gather_fixed(torch.cat(bufs, dim=0), world)
-        return sum(r[0] for r in res), sum(r[1] for r in res), sum(r[2] for r in res)
+        res = list(pool.map(one_unit, work))
+        if world > 1:                                  # the one exchange: ONE all-gather of all units' tables
+            cur = torch.cuda.current_stream(dev)
+            for send, done in res:
+                cur.wait_event(done)
+                send.record_stream(cur)
+            return D.gather_fixed(D.concat_fixed([r[0] for r in res]), world)
+        return None
 
     for _ in range(a.warmup):
         step()
+        torch.cuda.synchronize()
+    for item in work:
+        item["ctx"].grid_time()
+    # the dominant kernel alone on the chip: fp64 grid launches of the middle unit back to back (first not counted)
+    mid = work[len(work) // 2]
+    alone = []
+    if not mixed:
+        with torch.cuda.stream(mid["stream"]):
+            for _ in range(4):
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e[0].record(mid["stream"])
+                mid["prob"].eval_grid(mid["k"], mid["W"])
+                e[1].record(mid["stream"])
+                alone.append(e)
+        torch.cuda.synchronize()
+        mid["ctx"].grid_time()
+    unshared = [e0.elapsed_time(e1) for e0, e1 in alone[1:]]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        nbr, nacc, nre = step()
+        buf = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # per-launch duration of the grid-march kernel: HIP events inside the library, on the stream of every launch
+    gt = [item["ctx"].grid_time() for item in work]
+    grid_ms_local = sum(t for t, _ in gt) / max(1, sum(n for _, n in gt))
+    # counts of the last step, read after the timed region
+    nbr = nacc = nre = 0
+    for item in work:
+        c = item["count"] if mixed else int(item["cnt"].item())
+        item["count"] = c
+        if c > item["cap"]:
+            raise SystemExit(f"unit {item['label']}: bracket count {c} exceeds the table capacity {item['cap']}")
+        nbr += c
+        nacc += int((item["table"][0]["flag"][:c] == 1).sum())
+        nre += item["nre"]
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    counts = torch.tensor([float(nbr), float(nacc), float(nre), float(len(orders) * n * n)], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([dt, grid_ms_local], dtype=torch.float64, device=cdev)
+    grid_points_local = sum(item["nk"] * item["nw"] for item in work)
+    counts = torch.tensor([float(nbr), float(nacc), float(nre), float(grid_points_local)], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
+    dt, grid_ms = float(tmax[0].item()), float(tmax[1].item())
     nbr, nacc, nre, grid_points = (int(x) for x in counts.tolist())
+    merged = None
+    if world > 1:
+        merged, _ = D.merge_units(buf, [item["xcap"] for item in work])
+        assert merged.shape[0] == nbr, (merged.shape, nbr)
+    elif a.dump_roots:
+        parts = []
+        for item in work:
+            c, t = item["count"], item["table"][0]
+            parts.append(np.stack([t["k"][:c].cpu().numpy(), t["w"][:c].cpu().numpy(), np.full(c, float(item["uid"])),
+                                   t["resid"][:c].cpu().numpy(), t["flag"][:c].cpu().numpy().astype(np.float64),
+                                   item["rows"][t["row"][:c].long()].cpu().numpy().astype(np.float64)], axis=1))
+        merged = np.concatenate(parts, axis=0)
     if rank == 0:
-        evals = grid_points + nre + nbr * refine_plan(nbr // 11)[2]
-        out = {"metric": "det(M) evals/sec + roots/sec, Cylinder / rotational flow m = 0..10 (BASELINE.json configs[4])",
-               "value": evals * a.steps / dt, "unit": "det-evals/s", "roots_per_s": nacc * a.steps / dt,
+        if a.dump_roots and merged is not None:
+            np.save(a.dump_roots, merged)
+        _, rounds, ev_per_bracket = refine_plan()
+        evals = grid_points + nre + nbr * ev_per_bracket
+        value = evals * a.steps / dt
+        launch_evals = mid["nk"] * mid["nw"]
+        nw = mid["nw"]
+        bytes_per_eval = 8.0 + 16.0 * (1.0 / nw + 1.0 / max(1, mid["nk"]))
+        achieved = launch_evals * bytes_per_eval / (grid_ms * 1e-3) / 1e9
+        nsteps = mid["eq"].n_nodes - 1
+        fam = int(mid["prob"].desc.geometry)
+        if mixed:
+            kernel = {0: "shoot_grid_f32_kernel<0,4,256,false,4>", 1: "shoot_grid_f32_kernel<1,4,256,true,2>"}[fam]
+        else:
+            kernel = mid["prob"].grid_kernel_name(nw)
+        un = float(np.mean(unshared)) if unshared else None
+        fp64_view, issue = valu_views(kernel, launch_evals, nsteps, grid_ms, un, a.workload, pmc_ok=(world == 1))
+        traffic, traffic_src = measured_traffic_per_launch(a.workload) if world == 1 else (None, None)
+        hist = np.sum([item["hist"] for item in work], axis=0).astype(float)
+        frac = {n: hist[i] / hist.sum() for i, n in enumerate(("ok", "leaky", "nonfinite", "continuum"))}
+        out = {"metric": f"det(M) evals/sec + roots/sec, {desc.split(' (BASELINE')[0]}",
+               "value": value, "unit": "det-evals/s", "roots_per_s": nacc * a.steps / dt,
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32 screening march + f64 re-evaluation / refinement" if mixed else "f64", "data": "synthetic",
-               "config": {"workload": "Cylinder / rotational flow (v_phi = 0.1 r), m = 0..10, 1024x1024 (k,omega) grid per "
-                                      "order, N = 2000 nodes (BASELINE.json configs[4]); NOT the headline",
-                          "precision": a.precision, "orders": 11, "grid_points_per_step": grid_points,
-                          "fp64_reevaluations_per_step": nre, "brackets_per_step": nbr, "roots_per_step": nacc,
-                          "parallelism": "single GPU" if world == 1 else f"orders m dealt round-robin to {world} ranks, one all-gather per step"}}
+               "config": {"workload": desc, "precision": "mixed" if mixed else "f64", "units": len(work),
+                          "grid_per_unit": [len(units[0][5]), len(units[0][6])], "k_rows_per_gpu_per_unit": mid["nk"],
+                          "interior_nodes": mid["eq"].n_nodes, "n_bisect": N_BISECT, "refine_sections": 17,
+                          "refine_rounds": rounds, "refine_polish_steps": REFINE_POLISH,
+                          "grid_points_per_step": grid_points, "fp64_reevaluations_per_step": nre,
+                          "brackets_per_step": nbr, "roots_per_step": nacc,
+                          "grid_point_status_fractions_rank0": frac,
+                          "gathered_root_records": int(merged.shape[0]) if (world > 1 and merged is not None) else 0,
+                          "exchange_capacity_records_per_unit": [item["xcap"] for item in work],
+                          "parallelism": "single GPU, one HIP stream per unit" if world == 1 else
+                                         f"k-rows of every unit strided over {world} ranks (equal point counts), one "
+                                         "RCCL all-gather of all units' root tables per step"},
+               "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                            "algorithmic_bytes_per_eval": bytes_per_eval,
+                            "algorithmic_bytes_per_launch": launch_evals * bytes_per_eval,
+                            "evals_per_launch": launch_evals, "avg_launch_ms": grid_ms, "avg_launch_ms_unshared": un,
+                            "launch_note": "avg_launch_ms: HIP events around every launch of the grid-march kernel in the timed "
+                                           "region, recorded by the library on the stream of the launch (es_context_grid_timer); "
+                                           "the units run on concurrent streams, so a launch shares the chip with the other "
+                                           "units' launches; avg_launch_ms_unshared: the fp64 launch of one unit alone, back to back",
+                            "note": "fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64 / valu_issue"}}
+        if fp64_view is not None:
+            out["valu_fp64"] = fp64_view
+        if issue is not None:
+            out["valu_issue"] = issue
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if share > 1:
+            out["emulated_share_of"] = share
+            out["projected_whole_job_value"] = value * share
+            out["config"]["parallelism"] = (f"PROJECTION: one GPU computing rank 0's tile of a {share}-GPU run (every {share}th "
+                                            "k-row of every unit, exchange buffers packed, no collective)")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -76,6 +76,16 @@ class Context:
     def synchronize(self):
         check(self.handle, self.lib.es_context_synchronize(self.handle))
 
+    def grid_timer(self, enable=True):
+        """HIP events around every grid-march launch of this context (es_context_grid_timer)."""
+        check(self.handle, self.lib.es_context_grid_timer(self.handle, 1 if enable else 0))
+
+    def grid_time(self):
+        """(summed ms, launches) of the grid-march kernels since the last call; synchronises the stream."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(self.handle, self.lib.es_context_grid_time(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.es_context_destroy(self.handle)
@@ -146,6 +156,8 @@ def _sig(lib):
     lib.es_last_error.restype = C.c_char_p
     lib.es_last_error.argtypes = [vp]
     lib.es_context_synchronize.argtypes = [vp]
+    lib.es_context_grid_timer.argtypes = [vp, i]
+    lib.es_context_grid_time.argtypes = [vp, C.POINTER(d), C.POINTER(i)]
     # (1) closed-form slab
     P = C.POINTER(SlabAnalyticParams)
     lib.es_slab_analytic_eval.argtypes = [vp, P, i, vp, i, vp, i, vp]
@@ -157,10 +169,13 @@ def _sig(lib):
     lib.es_shoot_eval_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, vp]
     lib.es_shoot_eval_grid_ex.argtypes = [vp, vp, vp, i, vp, i, i, i, vp, vp, vp]
     lib.es_shoot_eval_points.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
+    lib.es_shoot_grid_shape.argtypes = [vp, vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
     lib.es_shoot_find_roots_mixed.argtypes = [vp, vp, vp, i, vp, i, i, i, d, vp, vp, C.POINTER(RootTable), C.POINTER(i),
                                               C.POINTER(i)]
+    lib.es_shoot_find_roots_async.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), vp]
     lib.es_root_table_pack.argtypes = [vp, C.POINTER(RootTable), i, d, vp, i, vp]
+    lib.es_root_table_pack_async.argtypes = [vp, C.POINTER(RootTable), vp, d, vp, i, vp]
     lib.es_worker_run.argtypes = [vp, vp, C.POINTER(WorkerSpec), vp, i, vp, i, vp, vp, i, vp]
     # (4) closed-form uniform cylinder; (5) eigenfunctions
     lib.es_cyl_uniform_eval.argtypes = [vp, C.POINTER(CylUniformParams), vp, i, vp, i, i, vp, vp, vp]

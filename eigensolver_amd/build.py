@@ -74,8 +74,11 @@ def _compile_and_link(lib, extra_flags, tag, verbose):
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
+    # ES_BUILD_ALL_SHAPES=1: the measuring build of tools/probe/time_grid_shapes.py -- every (points per lane, waves per
+    # SIMD) launch shape of the grid kernel that ES_GRID_SHAPE can name, not only the ones the tables select
+    extra = ["-DES_ALL_GRID_SHAPES"] if os.environ.get("ES_BUILD_ALL_SHAPES") == "1" else []
     if force or needs_build(LIB):
-        _compile_and_link(LIB, [], "", verbose)
+        _compile_and_link(LIB, extra, "", verbose)
     if force or needs_build(LIB_IEEE):
         _compile_and_link(LIB_IEEE, ["-DES_IEEE_DIVISION"], ".ieee", verbose)
     return LIB

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
+#include <vector>
 #include "../../include/eigensolver_amd.h"
 
 struct es_context {
@@ -23,7 +25,14 @@ struct es_context {
   // dead flags behind it
   int* d_cols = nullptr;           size_t cols_cap = 0;
   uint8_t* d_coldead = nullptr;
+  // es_context_grid_timer: event pairs around the launches of the dominant (grid march) kernels on this stream
+  bool timer_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timer_events;
 };
+
+// Bracket a launch of a grid-march kernel with HIP events on the context's stream (no-ops unless the timer is on).
+void es_timer_begin(es_context* ctx);
+void es_timer_end(es_context* ctx);
 
 #define ES_HIP_CHECK(ctx, expr)                                                                 \
   do {                                                                                          \
@@ -53,6 +62,8 @@ int es_ensure_scan_scratch(es_context* ctx, size_t cells);
 //   step 2: exclusive scan of block_counts -> offsets, total
 // Returns the total through ctx->h_total after a stream sync.
 int es_scan_block_counts(es_context* ctx, int nblocks, int* h_total_out);
+// The scan alone, enqueued: offsets in ctx->d_block_counts, total in ctx->d_total, nothing read back.
+int es_scan_block_counts_async(es_context* ctx, int nblocks);
 
 // Position of a flagged cell inside the ordered output, from the masks and the scanned block offsets.
 __device__ __forceinline__ int es_cell_rank(const uint64_t* __restrict__ masks, const int* __restrict__ block_off,

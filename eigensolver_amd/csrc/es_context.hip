@@ -56,7 +56,46 @@ extern "C" int es_context_destroy(es_context* ctx) {
   if (ctx->d_coldead) (void)hipFree(ctx->d_coldead);
   if (ctx->d_total) (void)hipFree(ctx->d_total);
   if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+  for (auto& e : ctx->timer_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete ctx;
+  return ES_SUCCESS;
+}
+
+void es_timer_begin(es_context* ctx) {
+  if (!ctx->timer_on) return;
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  (void)hipEventRecord(a, ctx->stream);
+  ctx->timer_events.emplace_back(a, b);
+}
+
+void es_timer_end(es_context* ctx) {
+  if (!ctx->timer_on || ctx->timer_events.empty()) return;
+  (void)hipEventRecord(ctx->timer_events.back().second, ctx->stream);
+}
+
+extern "C" int es_context_grid_timer(es_context* ctx, int enable) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ctx->timer_on = enable != 0;
+  return ES_SUCCESS;
+}
+
+extern "C" int es_context_grid_time(es_context* ctx, double* h_total_ms, int* h_launches) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, h_total_ms && h_launches, "null pointer");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double total = 0.0;
+  int n = 0;
+  for (auto& e : ctx->timer_events) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { total += (double)ms; ++n; }
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  ctx->timer_events.clear();
+  *h_total_ms = total;
+  *h_launches = n;
   return ES_SUCCESS;
 }
 
@@ -138,9 +177,15 @@ __global__ __launch_bounds__(1024) void es_block_scan_kernel(int* __restrict__ c
   if (tid == 0) *total = carry;
 }
 
-int es_scan_block_counts(es_context* ctx, int nblocks, int* h_total_out) {
+int es_scan_block_counts_async(es_context* ctx, int nblocks) {
   hipLaunchKernelGGL(es_block_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_block_counts, nblocks, ctx->d_total);
   ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
+}
+
+int es_scan_block_counts(es_context* ctx, int nblocks, int* h_total_out) {
+  int rc = es_scan_block_counts_async(ctx, nblocks);
+  if (rc) return rc;
   ES_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   *h_total_out = *ctx->h_total;

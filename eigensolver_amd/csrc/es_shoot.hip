@@ -1,21 +1,27 @@
-// K3/K4/K5: shooting evaluation of D(k, omega) on a (k, omega) grid, bracket detection, 9-section + secant refinement
+// K3/K4/K5: shooting evaluation of D(k, omega) on a (k, omega) grid, bracket detection, 17-section + secant refinement
 // and ordered root compaction.  See es_shoot_device.hpp for the arithmetic and include/eigensolver_amd.h for the
 // reference lines each entry point replaces.
 //
 // Kernel layout (DESIGN.md section "kernels"):
-//  * shoot_grid_kernel<FAM, PTS, MAXT, TRACK>: one workgroup per k-row, omega along the lanes (PTS points per lane, strided by
-//    the workgroup size so the 8-byte D stores of a wave are one contiguous 512 B segment).  k is workgroup
-//    uniform, so everything that depends on (node, k, m) but not on omega is computed ONCE per row into an LDS
-//    table, chunk by chunk (CH RK4 steps per chunk); every lane then reads the same LDS address (broadcast).
+//  * shoot_grid_kernel<FAM, PTS, MAXT, TRACK, WPE>: one workgroup per tile = (k-row, omega-segment of T * PTS points), omega
+//    along the lanes (PTS points per lane, strided by the workgroup size so the 8-byte D stores of a wave are one
+//    contiguous 512 B segment).  k is workgroup uniform, so everything that depends on (node, k, m) but not on omega is
+//    computed ONCE per tile into an LDS table, chunk by chunk (CH RK4 steps per chunk); every lane then reads the same
+//    LDS address (broadcast).  Launch shapes per family: pick_shape().
 //  * shoot_points_kernel<FAM>: one (k, omega) pair per lane with unrelated k: the k-independent base table is
 //    staged in LDS chunk by chunk (es_shoot_shared.hpp: shoot_point), node entries are formed per lane.
 //  * bracket_flag_kernel: sign change against the omega-neighbour through __shfl_down (lane 63 reads the halo
 //    element), ballot masks + per-block counts; bracket_emit_kernel writes the ordered bracket list.
-//  * refine_kernel: 8 lanes per bracket, 9-section rounds steered by a wave ballot (uniform trip count -> no
-//    divergence), final classification with the reference's acceptance measure.
+//  * refine_kernel<FAM, LANES, CHR>: LANES = 16 lanes per bracket, 17-section rounds steered by a wave ballot (uniform
+//    trip count -> no divergence); refine_polish_kernel: two secant steps with one lane per bracket and the final
+//    classification with the reference's acceptance measure.  The bracket count may stay on the device
+//    (es_shoot_find_roots_async).
+//  * shoot_grid_f32_kernel: fp32 screening march of es_shoot_find_roots_mixed.
 #include <vector>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <type_traits>
 
 #include "es_shoot_shared.hpp"
 
@@ -85,6 +91,30 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
       SignTrack trk[PTS];
       bool inr[PTS];
       int iwp[PTS];
+      // exterior closed form first: here nothing of the march is live, so the ~100 VGPRs of the Bessel code overlap with
+      // nothing and only its results are carried through the march (no call frame).
+      // a wave none of whose points has an evanescent exterior (leaky / non-finite: D is NaN whatever the march gives)
+      // only takes part in the LDS staging and the barriers
+      ExteriorLite X[PTS];
+      bool lane_live = false;
+      if (STASH) {
+        // ONE copy of the exterior code, executed PTS times (not unrolled): the results go to LDS at once, the frequency
+        // is formed again for the march below (same operations, same value) -- so the register cap of the shape costs no
+        // spill in the Bessel code and the kernel carries one copy of it instead of PTS
+#pragma unroll 1
+        for (int p = 0; p < PTS; ++p) {
+          const int ic = w0 + p * T + (int)threadIdx.x;
+          const bool in = ic < ncols;
+          const int iw = in ? (opts.cols ? opts.cols[1 + ic] : ic) : 0;
+          const double wp = in ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
+          const ExteriorLite Xp = exterior_lite(P, k, wp, wp);
+          // with ES_EVAL_SKIP_CONTINUUM a point inside a continuum band (known before the march) is not worth a march
+          const bool dead = opts.skip && !TRACK && band_crossed(P, k, wp);
+          lane_live = lane_live || (in && Xp.status == ES_PT_OK && !dead);
+          double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;   // lane-contiguous: conflict-free
+          xs[0] = Xp.outer; xs[MAXT] = Xp.yb; xs[2 * MAXT] = Xp.Oe; xs[3 * MAXT] = (double)Xp.status;
+        }
+      }
 #pragma unroll
       for (int p = 0; p < PTS; ++p) {
         const int ic = w0 + p * T + (int)threadIdx.x;
@@ -92,21 +122,12 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
         iwp[p] = inr[p] ? (opts.cols ? opts.cols[1 + ic] : ic) : 0;
         w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iwp[p]) : 1.0;
       }
-      // exterior closed form first: here only w[] is live, so the ~100 VGPRs of the Bessel code overlap with nothing
-      // and only its three results per point are carried through the march (no call frame, no scratch)
-      // a wave none of whose points has an evanescent exterior (leaky / non-finite: D is NaN whatever the march gives)
-      // only takes part in the LDS staging and the barriers
-      ExteriorLite X[PTS];
-      bool lane_live = false;
+      if (!STASH) {
 #pragma unroll
-      for (int p = 0; p < PTS; ++p) {
-        X[p] = exterior_lite(P, k, w[p], w[p]);
-        // with ES_EVAL_SKIP_CONTINUUM a point inside a continuum band (known before the march) is not worth a march
-        const bool dead = opts.skip && !TRACK && band_crossed(P, k, w[p]);
-        lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK && !dead);
-        if (STASH) {                                   // parked at once: not live during the next Bessel evaluation
-          double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;
-          xs[0] = X[p].outer; xs[MAXT] = X[p].yb; xs[2 * MAXT] = X[p].Oe; xs[3 * MAXT] = (double)X[p].status;
+        for (int p = 0; p < PTS; ++p) {
+          X[p] = exterior_lite(P, k, w[p], w[p]);
+          const bool dead = opts.skip && !TRACK && band_crossed(P, k, w[p]);
+          lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK && !dead);
         }
       }
       const bool wave_live = __any(lane_live);
@@ -195,7 +216,12 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
         const int iw = iwp[p];
         const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X[p], zp[p], zq[p], ef);
         double D, rel; uint8_t st;
-        finish_point(P, M, X[p], TRACK ? trk[p].crossed() : band_crossed(P, k, w[p]), D, rel, st);
+        const bool crossed = TRACK ? trk[p].crossed() : band_crossed(P, k, w[p]);
+        finish_point(P, M, X[p], crossed, D, rel, st);
+        // a band point of ES_EVAL_SKIP_CONTINUUM may not have been marched at all (a wave or workgroup of dead points keeps
+        // z = 0, the boundary algebra gives 0/0 and finish_point says NONFINITE): its status is CONTINUUM, as the header
+        // documents (the fp32 screening kernel does the same)
+        if (opts.skip && !TRACK && crossed && X[p].status == ES_PT_OK) st = ES_PT_CONTINUUM;
         if (opts.skip && st == ES_PT_CONTINUUM) { D = NAN; rel = NAN; }
         const size_t o = (size_t)row * nw + iw;
         Dout[o] = D;
@@ -362,11 +388,14 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
 // rounds shrink the bracket at least as much as n_bisect bisections would; uniform trip count, no divergence.
 // The kernel is bound by the number of SEQUENTIAL marches of one point per lane, not by throughput, as long as the
 // launch stays below a few waves per SIMD: LANES = 16 (17-section, 4 rounds for n_bisect = 16) up to 32768 brackets,
-// LANES = 8 (9-section, 6 rounds; fewest evaluations in total) beyond; refine_sections() is the rule, mirrored by the port.
-// (A 65-section rule for small bracket counts -- one wave per bracket, 3 rounds -- was tried for the k-tiles of a
-// multi-GPU run and dropped: the rule must not depend on how a grid is tiled, or the merged root table of N ranks is
-// no longer the N = 1 table bit for bit.  The threshold below is far above any tile of the bench.)
-__host__ __device__ inline int refine_sections(long n_brackets) { return n_brackets <= 32768 ? 17 : 9; }
+// The section rule is FIXED (17-section, 16 lanes per bracket: 4 rounds for n_bisect = 16): it must not depend on the bracket
+// count of the call, or a grid tiled over N ranks -- fewer brackets per call -- would be refined by another rule than
+// the same grid on one rank and the merged root table would no longer be the N = 1 table bit for bit (round 2 switched
+// to 9-section above 32768 brackets per call; the device-side count of es_shoot_find_roots_async could not even know).
+// ES_REFINE_SECTIONS = 5 / 9 / 17 in the environment selects another rule for the whole process (tuning aid, honoured by
+// the port); the port mirrors the default.
+constexpr int kRefineSections = 17;
+constexpr int kSharedMin = 2048;   // brackets from which the wave-shared node entries are used (untwisted cylinder)
 
 // Workgroups of 4 waves share ONE LDS staging of the (k-independent) base table: 3.6 KB of LDS per wave instead of 14.4,
 // so occupancy is no longer LDS-bound and the compiler aims for the register footprint of the point kernel -- which is
@@ -379,8 +408,12 @@ constexpr int REFINE_WAVES = 4;
 // shared by the LANES lanes of the bracket (shoot_point_wavegroup); CHR = 0: every lane forms its own (shoot_point).
 template <int FAM, int LANES, int CHR = 0, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, int n, int n_rounds,   // d_lo / d_hi alias table columns
-                                                    int n_polish, double tol_percent) {
+void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n, int n_max,
+                   int n_rounds, int n_polish, double tol_percent) {                      // d_lo / d_hi alias table columns
+  // bracket count: from device memory (es_shoot_find_roots_async: the host never reads it; the launch is sized for
+  // n_max = the table capacity and the workgroups beyond the count return at once) or n_max itself
+  const int n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
+  if ((int)(blockIdx.x * REFINE_WAVES * (64 / LANES)) >= n) return;                       // workgroup-uniform
   constexpr int GROUPS = 64 / LANES;
   constexpr int WTBL = GROUPS * (2 * (CHR > 0 ? CHR : 1) + 1) * FamTraits<FAM>::NE;      // doubles per wave
   __shared__ double es_point_lds[CHR > 0 ? REFINE_WAVES * WTBL : FamTraits<FAM>::NB * (2 * es_shoot_shared::CH + 1)];
@@ -453,9 +486,11 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, in
 // lanes of a bracket evaluate the same secant point, so two of its six marches do a sixteenth of the work they cost.
 template <int FAM, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void refine_polish_kernel(ShootDev P, es_root_table tab, const double* d_lo, const double* d_hi, int n, int n_polish,
-                          double tol_percent) {                      // d_lo / d_hi alias table columns (no restrict)
+void refine_polish_kernel(ShootDev P, es_root_table tab, const double* d_lo, const double* d_hi, const int* __restrict__ d_n,
+                          int n_max, int n_polish, double tol_percent) {   // d_lo / d_hi alias table columns (no restrict)
   ES_POINT_LDS(FAM);
+  const int n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
+  if ((int)(blockIdx.x * (64 * REFINE_WAVES)) >= n) return;                               // workgroup-uniform
   const int i = blockIdx.x * (64 * REFINE_WAVES) + (int)threadIdx.x;
   const bool in = i < n;
   const double k = in ? tab.d_k[i] : 1.0;
@@ -856,18 +891,76 @@ int check_problem(es_context* ctx, const es_problem* prob) {
   return ES_SUCCESS;
 }
 
-// Launch geometry of the grid kernel: workgroup = one k-row, threads cover omega, PTS points per lane.
-//   variant 0: PTS = 2, up to 1024 threads (<=128 VGPR, 4 waves/SIMD)
-//   variant 1: PTS = 4, up to  512 threads (<=256 VGPR, 2 waves/SIMD, no scratch)  -- default for rows >= 2048 wide
-//   variant 2: PTS = 1, up to 1024 threads                                         -- narrow rows (worker batches)
-//   variant 3: PTS = 4, up to  256 threads, registers capped at 168 (amdgpu_waves_per_eu 3): three workgroups per
-//              CU = 3 waves/SIMD; the spills this costs sit in the exterior, outside the march.  Default for the
-//              untwisted cylinder on rows >= 2048 wide (4096^2: 24.0 ms against 25.2 ms for variant 1); the other
-//              families need more registers per point and lose (twisted cylinder: 14.3 ms against 7.9 ms at 1024^2).
-// Four points per lane (variants 1, 3) are the fastest on wide rows (FAM_CYL0, 4096^2: 26.2 ms against 27.6 / 30.0 ms
-// for variants 0 / 2 at the time of r1e): independent points cover the fp64 dependency chains and share the
-// broadcast LDS reads.
-// ES_GRID_VARIANT in the environment overrides the default (tuning aid).
+// Launch shape of the grid kernel = (PTS points per lane, WPE waves per SIMD the register cap allows).  Every shape runs
+// workgroups of at most 256 threads (one wave per SIMD of a CU) over tiles (k-row, omega-segment of T * PTS points) and
+// parks the exterior results in LDS during the march, so the register cap 512 / WPE is the march loop's alone:
+//   WPE = 2 -> 256 VGPRs, 3 -> 168, 4 -> 128.
+// Round 2 picked between 1024-, 512- and 256-thread shapes by row width only; the 1024-thread ones (128 VGPRs by launch
+// bounds) spilled 12 - 89 VGPRs inside the march loop of every family but the untwisted cylinder with one point per lane --
+// exactly the shapes BASELINE configs[1] and configs[4] (1024 columns) selected.  Now every family has its own table of
+// spill-free shapes (tools/codeobj_table.py prints registers / spills / LDS of each built instantiation;
+// tests/test_codeobj.py fails on a spill in a shape the table selects) and the cost of a point in each of them, measured
+// on the GPU (tools/probe/time_grid_shapes.py -> profiles/r3_grid_shapes.json); pick_shape() minimises
+// padded points x cost per point for the row width at hand.  ES_GRID_SHAPE="pts,wpe" in the environment overrides it
+// (tuning aid).  D does not depend on the shape: a point's arithmetic is the same in all of them
+// (tests/test_shoot_gpu.py::test_grid_shapes_bit_identical).
+struct GridShape { int pts, wpe; };
+
+// Per family, indexed by points per lane (1, 2, 4): the register cap paired with it and the relative cost of one point,
+// measured on the grids of the BASELINE configs (profiles/r3_grid_shapes.json: min of three launches, MI355X; all nine
+// (points, cap) combinations per family bit-identical).  Reading of that table: with the spills gone the shapes of one
+// family lie within 15 % of each other -- every one of them runs at 0.85 - 1.0 of the issue bound of its own instruction
+// stream (tools/isa_loop_count.py) -- so the choice is about padding (a row of 384 frequencies fills 2 points x 192 lanes
+// exactly, 4 points x 128 lanes waste a quarter) and about not spilling; four points per lane share the LDS reads and
+// the loop overhead best.  WPE = 4 is used where the kernel fits 128 registers without a spill.
+template <int FAM> struct ShapeTable;
+template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.14, 1.08, 0, 1.0}; };
+// twisted cylinder: equal speed at 1, 2 and 4 points per lane (517 issue cycles per point-step either way); two points per
+// lane need 212 registers, four would need 260 (256: a handful of values spilled around the exterior code)
+template <> struct ShapeTable<FAM_CYLT>  { static constexpr int wpe[5] = {0, 3, 2, 0, 2}; static constexpr double cost[5] = {0, 1.02, 1.0, 0, 1.01}; };
+template <> struct ShapeTable<FAM_SLABD> { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.14, 1.09, 0, 1.0}; };
+template <> struct ShapeTable<FAM_SLABF> { static constexpr int wpe[5] = {0, 3, 3, 0, 3}; static constexpr double cost[5] = {0, 1.11, 1.06, 0, 1.0}; };
+
+inline int shape_threads(int nw, int pts) {
+  int T = ((nw + pts - 1) / pts + 63) / 64 * 64;
+  if (T < 64) T = 64;
+  if (T > 256) T = 256;
+  return T;
+}
+
+template <int FAM>
+GridShape pick_shape(int nw, bool track) {
+  GridShape best{4, 2};
+  double best_cost = 1e300;
+  for (int pts : {4, 2, 1}) {
+    const int T = shape_threads(nw, pts);
+    const long span = (long)T * pts;
+    const long padded = (nw + span - 1) / span * span;
+    const double c = (double)padded * ShapeTable<FAM>::cost[pts];
+    if (c < best_cost) { best_cost = c; best = GridShape{pts, ShapeTable<FAM>::wpe[pts]}; }
+  }
+  // per-node sign tracking of a band family (profiles whose continuum intervals do not overlap): 6 - 12 more registers
+  // per point; the 256-register shapes hold them without a spill
+  if (track && fam_has_bands<FAM>()) best.wpe = 2;
+  if (const char* ev = getenv("ES_GRID_SHAPE")) {
+    int p = 0, w = 0;
+    if (sscanf(ev, "%d,%d", &p, &w) == 2 && (p == 1 || p == 2 || p == 4) && w >= 2 && w <= 4) best = GridShape{p, w};
+  }
+  return best;
+}
+
+// which (PTS, WPE, TRACK) instantiations are built: the shapes the tables select, the tracking fall-backs at WPE = 2, and
+// (-DES_ALL_GRID_SHAPES, the measuring build of tools/probe/time_grid_shapes.py) everything ES_GRID_SHAPE can name
+template <int FAM, int PTS, int WPE, bool TRACK>
+constexpr bool shape_built() {
+#if defined(ES_ALL_GRID_SHAPES)
+  return true;
+#else
+  if (TRACK && fam_has_bands<FAM>()) return WPE == 2;
+  return ShapeTable<FAM>::wpe[PTS] == WPE;
+#endif
+}
+
 template <int FAM>
 int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
                 int w_mode, double* d_D, double* d_rel, uint8_t* d_status, int flags = 0) {
@@ -898,57 +991,49 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
     ES_HIP_CHECK(ctx, hipGetLastError());
     opts.cols = ctx->d_cols;
   }
-  int variant = (nw >= 2048) ? ((FAM == FAM_CYL0) ? 3 : 1) : ((nw >= 1024) ? 0 : 2);
-  if (const char* ev = getenv("ES_GRID_VARIANT")) variant = atoi(ev);
-  auto roundT = [](int pts_needed, int maxT) {
-    int T = (pts_needed + 63) / 64 * 64;
-    if (T < 64) T = 64;
-    if (T > maxT) T = maxT;
-    return T;
-  };
   // families with connected continuum bands: no per-node sign tracking (band_crossed)
-  const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
-#define ES_LAUNCH_GRID_W(PTS, MAXT, T, WPE)                                                                         \
-  do {                                                                                                              \
-    const long tiles_ = (long)nk * ((nw + (T) * (PTS) - 1) / ((T) * (PTS)));                                        \
-    const int grid = (int)(tiles_ < (1L << 22) ? tiles_ : (1L << 22));                                              \
-    if (bands)                                                                                                      \
-      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, !fam_has_bands<FAM>(), WPE>), dim3(grid), dim3(T), 0,   \
-                         ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);             \
-    else                                                                                                            \
-      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, MAXT, true, WPE>), dim3(grid), dim3(T), 0, ctx->stream,       \
-                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);                          \
-  } while (0)
-#define ES_LAUNCH_GRID(PTS, MAXT, T) ES_LAUNCH_GRID_W(PTS, MAXT, T, 0)
-  if (variant == 3 && FAM != FAM_CYL0) variant = 1;          // the register-capped shape exists for FAM_CYL0 only
-  if (variant == 3) {
-    if constexpr (FAM == FAM_CYL0) {
-      const int T = roundT((nw + 3) / 4, 256);
-      if (opts.cols && T > 64) {
-        // compacted launch: full segments in 4-wave workgroups, the remainder of each row in one-wave workgroups
-        opts.part = 1;
-        ES_LAUNCH_GRID_W(4, 256, T, 3);
-        opts.part = 2;
-        opts.main_span = 4 * T;
-        const long tiles2 = (long)nk * (T / 64);
-        hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 64, false, 2>), dim3((int)(tiles2 < (1L << 22) ? tiles2 : (1L << 22))),
-                           dim3(64), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
-      } else {
-        ES_LAUNCH_GRID_W(4, 256, T, 3);
+  const bool track = !(fam_has_bands<FAM>() && prob->dev.use_bands);
+  GridShape shape = pick_shape<FAM>(nw, track);
+  const int T = shape_threads(nw, shape.pts);
+  const long tiles = (long)nk * ((nw + (long)T * shape.pts - 1) / ((long)T * shape.pts));
+  const int grid = (int)(tiles < (1L << 22) ? tiles : (1L << 22));
+  bool launched = false;
+  es_timer_begin(ctx);
+  auto one = [&](auto pts_c, auto wpe_c, auto track_c) {
+    constexpr int PTS = decltype(pts_c)::value, WPE = decltype(wpe_c)::value;
+    constexpr bool TRACK = decltype(track_c)::value;
+    if constexpr (shape_built<FAM, PTS, WPE, TRACK>() && (TRACK || fam_has_bands<FAM>())) {
+      if (launched || shape.pts != PTS || shape.wpe != WPE || track != TRACK) return;
+      launched = true;
+      if constexpr (FAM == FAM_CYL0 && PTS == 4 && !TRACK) {
+        if (opts.cols && T > 64) {
+          // compacted launch: full segments in 4-wave workgroups, the remainder of each row in one-wave workgroups
+          opts.part = 1;
+          hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, 256, TRACK, WPE>), dim3(grid), dim3(T), 0, ctx->stream,
+                             prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
+          opts.part = 2;
+          opts.main_span = 4 * T;
+          const long tiles2 = (long)nk * (T / 64);
+          hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 64, false, 2>), dim3((int)(tiles2 < (1L << 22) ? tiles2 : (1L << 22))),
+                             dim3(64), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
+          return;
+        }
       }
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, 256, TRACK, WPE>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev,
+                         d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
     }
-  } else if (variant == 1) {
-    const int T = roundT((nw + 3) / 4, 512);
-    ES_LAUNCH_GRID(4, 512, T);
-  } else if (variant == 0) {
-    const int T = roundT((nw + 1) / 2, 1024);
-    ES_LAUNCH_GRID(2, 1024, T);
-  } else {
-    const int T = roundT(nw, 1024);
-    ES_LAUNCH_GRID(1, 1024, T);
+  };
+  using std::integral_constant;
+#define ES_SHAPE(P_, W_)                                                                                            \
+  one(integral_constant<int, P_>{}, integral_constant<int, W_>{}, integral_constant<bool, false>{});                \
+  one(integral_constant<int, P_>{}, integral_constant<int, W_>{}, integral_constant<bool, true>{});
+  ES_SHAPE(4, 2) ES_SHAPE(4, 3) ES_SHAPE(4, 4) ES_SHAPE(2, 2) ES_SHAPE(2, 3) ES_SHAPE(2, 4) ES_SHAPE(1, 2) ES_SHAPE(1, 3) ES_SHAPE(1, 4)
+#undef ES_SHAPE
+  es_timer_end(ctx);
+  if (!launched) {
+    ctx->last_error = "grid launch shape not built (ES_GRID_SHAPE names a shape outside this build)";
+    return ES_ERR_UNSUPPORTED;
   }
-#undef ES_LAUNCH_GRID
-#undef ES_LAUNCH_GRID_W
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;
 }
@@ -962,11 +1047,13 @@ int launch_points(es_context* ctx, const es_problem* prob, const double* d_k, co
   return ES_SUCCESS;
 }
 
+// d_n: bracket count in device memory (nullptr: n_max IS the count); n_max: launch bound (count known on the host, or the
+// table capacity); n_hint: what the count is expected to be (selects between variants that give identical results)
 template <int FAM>
-int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, double* d_lo, double* d_hi, int n,
-                  int n_bisect, double tol) {
+int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, double* d_lo, double* d_hi,
+                  const int* d_n, int n_max, int n_hint, int n_bisect, double tol) {
   // (LANES+1)-section rounds equivalent to n_bisect halvings: (LANES+1)^R >= 2^n_bisect
-  int sections = refine_sections(n);
+  int sections = kRefineSections;
   if (const char* ev = getenv("ES_REFINE_SECTIONS")) {            // tuning aid, honoured by the port as well: 5, 9 or 17
     const int v = atoi(ev);
     if (v == 5 || v == 9 || v == 17) sections = v;
@@ -977,30 +1064,48 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   // the ends of the narrowed bracket from one kernel to the other)
   const int np = (ES_REFINE_POLISH > 0 && rounds > 0) ? -1 : ES_REFINE_POLISH;
   // 17-section of the untwisted cylinder with np < 0 (sections only): node entries shared inside the wave, 32 steps per
-  // chunk (14.6 KB of LDS per wave).  Measured, same box: one-stream step 22.19 against 22.55 ms, pipelined 21.47 against
-  // 21.74 ms, the 512-row tile unchanged.  The twisted family (16 entries per node: 17 KB per wave at 16 steps per chunk,
-  // one workgroup per CU) lost 7 % on configs[4] and keeps per-lane entries.
+  // chunk (14.6 KB of LDS per wave).  Bit-identical to the per-lane entries, so the choice may follow the bracket count:
+  // the 58 KB workgroups pay off when the launch is several waves per SIMD deep (N = 1 bench: 6 561 brackets) and lose
+  // on the few hundred brackets of a k-tile, where they wait for LDS beside the grid workgroups of the next step
+  // (ES_REFINE_SHARED_MIN, default kSharedMin; measured in profiles/README.md, round 3).  The twisted family (16
+  // entries per node: 17 KB per wave at 16 steps per chunk, one workgroup per CU) lost 7 % on configs[4] and keeps
+  // per-lane entries.
   constexpr int CHR = (FAM == FAM_CYL0) ? 32 : 0;
-  const bool shared_entries = CHR > 0 && np < 0 && !getenv("ES_REFINE_PRIVATE_ENTRIES");
+  int shared_min = kSharedMin;
+  if (const char* ev = getenv("ES_REFINE_SHARED_MIN")) shared_min = atoi(ev);
+  const bool shared_entries = CHR > 0 && np < 0 && n_hint >= shared_min && !getenv("ES_REFINE_PRIVATE_ENTRIES");
+  auto blocks = [&](int per_wg) { return dim3((n_max + per_wg - 1) / per_wg); };
   if (sections == 17 && shared_entries)
-    hipLaunchKernelGGL((refine_kernel<FAM, 16, CHR>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
+    hipLaunchKernelGGL((refine_kernel<FAM, 16, CHR>), blocks(4 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
   else if (sections == 17)
-    hipLaunchKernelGGL((refine_kernel<FAM, 16>), dim3((n + 4 * REFINE_WAVES - 1) / (4 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
+    hipLaunchKernelGGL((refine_kernel<FAM, 16>), blocks(4 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
   else if (sections == 9)
-    hipLaunchKernelGGL((refine_kernel<FAM, 8>), dim3((n + 8 * REFINE_WAVES - 1) / (8 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
+    hipLaunchKernelGGL((refine_kernel<FAM, 8>), blocks(8 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
   else
-    hipLaunchKernelGGL((refine_kernel<FAM, 4>), dim3((n + 16 * REFINE_WAVES - 1) / (16 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, rounds, np, tol);
+    hipLaunchKernelGGL((refine_kernel<FAM, 4>), blocks(16 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
   ES_HIP_CHECK(ctx, hipGetLastError());
   if (np < 0) {
-    hipLaunchKernelGGL((refine_polish_kernel<FAM>), dim3((n + 64 * REFINE_WAVES - 1) / (64 * REFINE_WAVES)),
-                       dim3(64 * REFINE_WAVES), 0, ctx->stream, prob->dev, tab, d_lo, d_hi, n, ES_REFINE_POLISH, tol);
+    hipLaunchKernelGGL((refine_polish_kernel<FAM>), blocks(64 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                       prob->dev, tab, d_lo, d_hi, d_n, n_max, ES_REFINE_POLISH, tol);
     ES_HIP_CHECK(ctx, hipGetLastError());
   }
   return ES_SUCCESS;
+}
+
+int dispatch_refine(es_context* ctx, const es_problem* prob, const es_root_table& tab, const int* d_n, int n_max, int n_hint,
+                    int n_bisect, double tol) {
+  // the d_w / d_resid columns double as scratch for D at the two bracket ends until refinement overwrites them
+  switch (prob->dev.family) {
+    case FAM_CYL0: return launch_refine<FAM_CYL0>(ctx, prob, tab, tab.d_w, tab.d_resid, d_n, n_max, n_hint, n_bisect, tol);
+    case FAM_CYLT: return launch_refine<FAM_CYLT>(ctx, prob, tab, tab.d_w, tab.d_resid, d_n, n_max, n_hint, n_bisect, tol);
+    case FAM_SLABD: return launch_refine<FAM_SLABD>(ctx, prob, tab, tab.d_w, tab.d_resid, d_n, n_max, n_hint, n_bisect, tol);
+    case FAM_SLABF: return launch_refine<FAM_SLABF>(ctx, prob, tab, tab.d_w, tab.d_resid, d_n, n_max, n_hint, n_bisect, tol);
+    default: return ES_ERR_UNSUPPORTED;
+  }
 }
 
 #define ES_DISPATCH_FAMILY(fam, CALL)                      \
@@ -1222,6 +1327,24 @@ extern "C" int es_shoot_eval_grid_ex(es_context* ctx, const es_problem* prob, co
 #undef CALL_GRID
 }
 
+extern "C" int es_shoot_grid_shape(es_context* ctx, const es_problem* prob, int nw, int* h_pts, int* h_wpe, int* h_track) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, h_pts && h_wpe && h_track && nw > 0, "shape query arguments");
+  GridShape g{0, 0};
+  bool track = true;
+  switch (prob->dev.family) {
+    case FAM_CYL0: track = !prob->dev.use_bands; g = pick_shape<FAM_CYL0>(nw, track); break;
+    case FAM_CYLT: g = pick_shape<FAM_CYLT>(nw, true); break;
+    case FAM_SLABD: track = !prob->dev.use_bands; g = pick_shape<FAM_SLABD>(nw, track); break;
+    case FAM_SLABF: track = !prob->dev.use_bands; g = pick_shape<FAM_SLABF>(nw, track); break;
+    default: return ES_ERR_UNSUPPORTED;
+  }
+  *h_pts = g.pts; *h_wpe = g.wpe; *h_track = track ? 1 : 0;
+  return ES_SUCCESS;
+}
+
 extern "C" int es_shoot_eval_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                                   const double* d_w, int nw, int w_mode, double* d_D, double* d_rel,
                                   uint8_t* d_status) {
@@ -1242,53 +1365,94 @@ extern "C" int es_shoot_eval_points(es_context* ctx, const es_problem* prob, con
 #undef CALL_PTS
 }
 
-extern "C" int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
-                                   const double* d_w, int nw, int w_mode, const double* d_D,
-                                   const uint8_t* d_status, int n_bisect, double tol_percent, es_root_table* table,
-                                   int* h_count) {
-  if (!ctx) return ES_ERR_INVALID_ARG;
-  int rc = check_problem(ctx, prob);
-  if (rc) return rc;
-  ES_REQUIRE(ctx, table && h_count, "null pointer");
-  ES_REQUIRE(ctx, nk >= 0 && nw >= 0 && n_bisect >= 0 && table->capacity >= 0, "negative size");
-  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
-  *h_count = 0;
+namespace {
+// flag + scan + emit + refine, everything enqueued, no host synchronisation: the bracket count stays in ctx->d_total
+int find_roots_enqueue(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
+                       int w_mode, const double* d_D, const uint8_t* d_status, int n_bisect, double tol_percent,
+                       const es_root_table* table) {
   const long cells = (long)nk * nw;
-  if (cells == 0) return ES_SUCCESS;
-  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
-  ES_REQUIRE(ctx, table->capacity == 0 || (table->d_k && table->d_w && table->d_w_lo && table->d_w_hi &&
-                                           table->d_resid && table->d_row && table->d_flag),
-             "null root table arrays");
-  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  rc = es_ensure_scan_scratch(ctx, (size_t)cells);
+  int rc = es_ensure_scan_scratch(ctx, (size_t)cells);
   if (rc) return rc;
   const int nblocks = (int)((cells + 255) / 256);
   hipLaunchKernelGGL(bracket_flag_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_D, d_status, nw, cells,
                      ctx->d_masks, ctx->d_block_counts);
   ES_HIP_CHECK(ctx, hipGetLastError());
-  int total = 0;
-  rc = es_scan_block_counts(ctx, nblocks, &total);
+  rc = es_scan_block_counts_async(ctx, nblocks);
   if (rc) return rc;
-  *h_count = total;
-  const int n = total < table->capacity ? total : table->capacity;
-  if (n > 0) {
-    // the d_w / d_resid columns double as scratch for D at the two bracket ends until refinement overwrites them
+  if (table->capacity > 0) {
     hipLaunchKernelGGL(bracket_emit_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w, nw, w_mode, cells,
                        d_D, ctx->d_masks, ctx->d_block_counts, *table, table->d_w, table->d_resid);
     ES_HIP_CHECK(ctx, hipGetLastError());
-#define CALL_REF(F) launch_refine<F>(ctx, prob, *table, table->d_w, table->d_resid, n, n_bisect, tol_percent)
-    int rr;
-    switch (prob->dev.family) {
-      case FAM_CYL0: rr = CALL_REF(FAM_CYL0); break;
-      case FAM_CYLT: rr = CALL_REF(FAM_CYLT); break;
-      case FAM_SLABD: rr = CALL_REF(FAM_SLABD); break;
-      case FAM_SLABF: rr = CALL_REF(FAM_SLABF); break;
-      default: rr = ES_ERR_UNSUPPORTED;
-    }
-#undef CALL_REF
-    if (rr) return rr;
+  }
+  return ES_SUCCESS;
+}
+
+int check_find_roots_args(es_context* ctx, const es_problem* prob, int nk, int nw, int w_mode, int n_bisect,
+                          const es_root_table* table) {
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, table, "null pointer");
+  ES_REQUIRE(ctx, nk >= 0 && nw >= 0 && n_bisect >= 0 && table->capacity >= 0, "negative size");
+  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  ES_REQUIRE(ctx, table->capacity == 0 || (table->d_k && table->d_w && table->d_w_lo && table->d_w_hi &&
+                                           table->d_resid && table->d_row && table->d_flag),
+             "null root table arrays");
+  return ES_SUCCESS;
+}
+}  // namespace
+
+extern "C" int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                   const double* d_w, int nw, int w_mode, const double* d_D,
+                                   const uint8_t* d_status, int n_bisect, double tol_percent, es_root_table* table,
+                                   int* h_count) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, h_count, "null pointer");
+  int rc = check_find_roots_args(ctx, prob, nk, nw, w_mode, n_bisect, table);
+  if (rc) return rc;
+  *h_count = 0;
+  if ((long)nk * nw == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  rc = find_roots_enqueue(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status, n_bisect, tol_percent, table);
+  if (rc) return rc;
+  // the one read-back of this entry point: the count it returns through a host pointer also sizes the refinement launch
+  ES_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int total = *ctx->h_total;
+  *h_count = total;
+  const int n = total < table->capacity ? total : table->capacity;
+  if (n > 0) {
+    rc = dispatch_refine(ctx, prob, *table, nullptr, n, n, n_bisect, tol_percent);
+    if (rc) return rc;
   }
   return total > table->capacity ? ES_ERR_CAPACITY : ES_SUCCESS;
+}
+
+extern "C" int es_shoot_find_roots_async(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                         const double* d_w, int nw, int w_mode, const double* d_D,
+                                         const uint8_t* d_status, int n_bisect, double tol_percent,
+                                         es_root_table* table, int32_t* d_count) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, d_count, "null pointer");
+  int rc = check_find_roots_args(ctx, prob, nk, nw, w_mode, n_bisect, table);
+  if (rc) return rc;
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if ((long)nk * nw == 0) {
+    ES_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(int32_t), ctx->stream));
+    return ES_SUCCESS;
+  }
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  rc = find_roots_enqueue(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status, n_bisect, tol_percent, table);
+  if (rc) return rc;
+  ES_HIP_CHECK(ctx, hipMemcpyAsync(d_count, ctx->d_total, sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  if (table->capacity > 0) {
+    // refinement sized for the table capacity, count taken from the caller's device word (ctx->d_total is reused by the
+    // next call on this context); the expected count for the variant choice: half the capacity (callers size the
+    // table at about twice the brackets they expect)
+    rc = dispatch_refine(ctx, prob, *table, d_count, table->capacity, table->capacity / 2, n_bisect, tol_percent);
+    if (rc) return rc;
+  }
+  return ES_SUCCESS;
 }
 
 
@@ -1298,6 +1462,7 @@ template <int FAM>
 int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
                     int w_mode, double* d_D, uint8_t* d_status) {
   if constexpr (FAM == FAM_CYL0 || FAM == FAM_CYLT) {
+    es_timer_begin(ctx);
     constexpr int PTS = 4;
     int T = ((nw + PTS - 1) / PTS + 63) / 64 * 64;
     if (T < 64) T = 64;
@@ -1348,6 +1513,7 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       }
     }
+    es_timer_end(ctx);
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_SUCCESS;
   } else {
@@ -1453,8 +1619,7 @@ extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob
     ES_HIP_CHECK(ctx, hipGetLastError());
     ES_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_total, ctx->d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     // 5. fp64 refinement
-    rc = (fam == FAM_CYL0) ? launch_refine<FAM_CYL0>(ctx, prob, *table, table->d_w, table->d_resid, n, n_bisect, tol_percent)
-                           : launch_refine<FAM_CYLT>(ctx, prob, *table, table->d_w, table->d_resid, n, n_bisect, tol_percent);
+    rc = dispatch_refine(ctx, prob, *table, nullptr, n, n, n_bisect, tol_percent);
     if (rc) return rc;
     ES_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     violations = *ctx->h_total;
@@ -1470,18 +1635,20 @@ extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob
 
 // ---- exchange record packing (multi-GPU root-table gather) ---------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void pack_records_kernel(es_root_table tab, int count, double m,
-                                                           const int64_t* __restrict__ rows_global, int cap,
+__global__ __launch_bounds__(256) void pack_records_kernel(es_root_table tab, int count_host, const int* __restrict__ d_count,
+                                                           double m, const int64_t* __restrict__ rows_global, int cap,
                                                            double* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;          // row of the send buffer: 0 = header, 1.. = records
   if (i > cap) return;
+  const int count = d_count ? *d_count : count_host;
   double* o = out + (size_t)i * 6;
   if (i == 0) {
     o[0] = (double)count; o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
     return;
   }
   const int r = i - 1;
-  const int n = count < cap ? count : cap;
+  int n = count < cap ? count : cap;
+  if (n > tab.capacity) n = tab.capacity;
   if (r < n) {
     const int row = tab.d_row[r];
     o[0] = tab.d_k[r]; o[1] = tab.d_w[r]; o[2] = m; o[3] = tab.d_resid[r]; o[4] = (double)tab.d_flag[r];
@@ -1500,7 +1667,20 @@ extern "C" int es_root_table_pack(es_context* ctx, const es_root_table* table, i
              "null root table arrays");
   ES_REQUIRE(ctx, (count < cap ? count : cap) <= table->capacity, "count exceeds the table");
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(pack_records_kernel, dim3((cap + 1 + 255) / 256), dim3(256), 0, ctx->stream, *table, count, m,
+  hipLaunchKernelGGL(pack_records_kernel, dim3((cap + 1 + 255) / 256), dim3(256), 0, ctx->stream, *table, count, nullptr, m,
+                     d_rows_global, cap, d_out);
+  ES_HIP_CHECK(ctx, hipGetLastError());
+  return ES_SUCCESS;
+}
+
+extern "C" int es_root_table_pack_async(es_context* ctx, const es_root_table* table, const int32_t* d_count, double m,
+                                        const int64_t* d_rows_global, int cap, double* d_out) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  ES_REQUIRE(ctx, table && d_out && d_count && cap >= 0, "pack arguments");
+  ES_REQUIRE(ctx, cap == 0 || (table->d_k && table->d_w && table->d_resid && table->d_row && table->d_flag),
+             "null root table arrays");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(pack_records_kernel, dim3((cap + 1 + 255) / 256), dim3(256), 0, ctx->stream, *table, 0, d_count, m,
                      d_rows_global, cap, d_out);
   ES_HIP_CHECK(ctx, hipGetLastError());
   return ES_SUCCESS;

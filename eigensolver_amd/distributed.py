@@ -70,23 +70,39 @@ N_FIELDS = 6
 
 def pack_fixed(roots, count, m, rows_global, cap, ctx=None):
     """(cap + 1, 6) send buffer on the device of `roots`; rows_global[i] = global k-row of local row i (int64 tensor).
-    With a library context (GPU tensors) the buffer is filled by ONE kernel (es_root_table_pack); the torch path is
-    the same layout for CPU tensors (gloo tests)."""
+    `count`: the bracket count, an int or (GPU path) the one-element int32 CUDA tensor of find_roots_async -- then
+    nothing is read back.  With a library context (GPU tensors) the buffer is filled by ONE kernel
+    (es_root_table_pack[_async]) on the CONTEXT's stream: the buffers it touches are allocated under that stream, so
+    the caching allocator cannot hand them out again while the kernel is pending, whatever torch's current stream is.
+    The torch path is the same layout for CPU tensors (gloo tests)."""
     import torch
     dev = roots["w"].device
     if ctx is not None and roots["w"].is_cuda:
         import ctypes as C
         from . import _lib
-        send = torch.empty((cap + 1, N_FIELDS), dtype=torch.float64, device=dev)
-        rt = _lib.RootTable(roots["k"].data_ptr(), roots["w"].data_ptr(), roots["w_lo"].data_ptr(),
-                            roots["w_hi"].data_ptr(), roots["resid"].data_ptr(), roots["row"].data_ptr(),
-                            roots["flag"].data_ptr(), int(roots["w"].numel()))
-        rg = rows_global.to(torch.int64).contiguous()
-        _lib.check(ctx.handle, ctx.lib.es_root_table_pack(ctx.handle, C.byref(rt), int(count), float(m),
-                                                          C.c_void_p(rg.data_ptr()), int(cap), _lib.ptr(send)))
+        if not (isinstance(rows_global, torch.Tensor) and rows_global.device == dev):
+            rows_global = torch.as_tensor(np.asarray(rows_global.cpu() if isinstance(rows_global, torch.Tensor) else rows_global),
+                                          device=dev)
+        with torch.cuda.stream(ctx.torch_stream):
+            send = torch.empty((cap + 1, N_FIELDS), dtype=torch.float64, device=dev)
+            rt = _lib.RootTable(roots["k"].data_ptr(), roots["w"].data_ptr(), roots["w_lo"].data_ptr(),
+                                roots["w_hi"].data_ptr(), roots["resid"].data_ptr(), roots["row"].data_ptr(),
+                                roots["flag"].data_ptr(), int(roots["w"].numel()))
+            rg = rows_global.to(torch.int64).contiguous()
+            if isinstance(count, torch.Tensor):
+                assert count.is_cuda and count.numel() == 1 and count.element_size() == 4
+                rc = ctx.lib.es_root_table_pack_async(ctx.handle, C.byref(rt), _lib.ptr(count), float(m),
+                                                      C.c_void_p(rg.data_ptr()), int(cap), _lib.ptr(send))
+            else:
+                rc = ctx.lib.es_root_table_pack(ctx.handle, C.byref(rt), int(count), float(m),
+                                                C.c_void_p(rg.data_ptr()), int(cap), _lib.ptr(send))
+            _lib.check(ctx.handle, rc)
+        for t_ in (send, rg):                       # consumers on other streams (the collective) order themselves by events
+            t_.record_stream(ctx.torch_stream)
         return send
     send = torch.zeros((cap + 1, N_FIELDS), dtype=torch.float64, device=dev)
-    n = min(int(count), cap, roots["w"].numel())
+    count = int(count)
+    n = min(count, cap, roots["w"].numel())
     send[0, 0] = float(count)
     if n > 0:
         send[1:n + 1, 0] = roots["k"][:n]
@@ -96,6 +112,24 @@ def pack_fixed(roots, count, m, rows_global, cap, ctx=None):
         send[1:n + 1, 4] = roots["flag"][:n].to(torch.float64)
         send[1:n + 1, 5] = rows_global[roots["row"][:n].long()].to(torch.float64)
     return send
+
+
+def exchange_capacity(count, group=None, floor=64):
+    """Capacity of the fixed-size exchange from the data: one all_reduce(MAX) of the ranks' bracket counts (warm-up,
+    outside the timed region), then the next power of two >= 2 x that.  Round 2 sent a fixed 32768 records per rank --
+    1.57 MB for about 820 records (39 KB) of a 512-row tile."""
+    import torch
+    import torch.distributed as dist
+    c = int(count)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([c], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        c = int(t.item())
+    cap = floor
+    while cap < 2 * c:
+        cap *= 2
+    return cap
 
 
 def gather_fixed(send, world=None, group=None):
@@ -116,15 +150,45 @@ def gather_fixed(send, world=None, group=None):
 
 
 def merge_fixed(buf):
-    """Gathered buffers -> (records sorted by (global row, position within the rank's table), counts per rank).  With
-    k-rows tiled across ranks this is exactly the single-GPU table order (rows outer, omega inner).  Host side."""
+    """Gathered buffers -> (records sorted by (unit = field 2, global row, position within the rank's table), counts per
+    rank).  With the k-rows of every unit (azimuthal order / mode) tiled across ranks this is exactly the single-GPU table
+    order (units outer, rows next, omega inner).  Host side."""
     b = buf.detach().cpu().numpy()
     cap = b.shape[1] - 1
     counts = [int(round(b[r, 0, 0])) for r in range(b.shape[0])]
     if max(counts) > cap:
         raise OverflowError(f"root table of a rank has {max(counts)} records, exchange capacity {cap}")
     rec = np.concatenate([b[r, 1:1 + c] for r, c in enumerate(counts)], axis=0) if sum(counts) else np.zeros((0, N_FIELDS))
-    order = np.argsort(rec[:, 5], kind="stable")
+    order = np.lexsort((rec[:, 5], rec[:, 2]))            # stable: primary key unit, secondary key global row
+    return rec[order], counts
+
+
+def concat_fixed(sends):
+    """Send buffers of several units (azimuthal orders / modes) of one rank -> ONE buffer for ONE all-gather per step:
+    the (cap_u + 1)-row slots back to back, each with its own header row, nothing read back on the host."""
+    import torch
+    return sends[0] if len(sends) == 1 else torch.cat(sends, dim=0)
+
+
+def merge_units(buf, caps):
+    """merge_fixed for gathered concat_fixed buffers: buf is (world, sum(cap_u + 1), 6), caps the slot capacities in
+    slot order.  Records sorted by (unit = field 2, global row, position), i.e. the single-GPU order of a run that
+    handles the units one after the other; counts[rank][slot]."""
+    b = buf.detach().cpu().numpy()
+    assert b.shape[1] == sum(c + 1 for c in caps), (b.shape, caps)
+    parts, counts = [], []
+    for r in range(b.shape[0]):
+        off, row_counts = 0, []
+        for c in caps:
+            n = int(round(b[r, off, 0]))
+            if n > c:
+                raise OverflowError(f"root table of a unit has {n} records, exchange capacity {c}")
+            parts.append(b[r, off + 1:off + 1 + n])
+            row_counts.append(n)
+            off += c + 1
+        counts.append(row_counts)
+    rec = np.concatenate(parts, axis=0) if parts and sum(map(len, parts)) else np.zeros((0, N_FIELDS))
+    order = np.lexsort((rec[:, 5], rec[:, 2]))
     return rec[order], counts
 
 

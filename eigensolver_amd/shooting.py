@@ -104,6 +104,14 @@ class ShootProblem:
         _lib.check(self.ctx.handle, rc)
         return (D, st, rel) if want_rel else (D, st)
 
+    def grid_kernel_name(self, nw):
+        """The instantiation of the grid kernel es_shoot_eval_grid launches for rows of nw frequencies (es_shoot_grid_shape),
+        spelled as tools/codeobj_table.py and rocprofv3 print it."""
+        pts, wpe, trk = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self.ctx.handle, self.ctx.lib.es_shoot_grid_shape(self.ctx.handle, self.handle, int(nw), C.byref(pts),
+                                                                     C.byref(wpe), C.byref(trk)))
+        return f"shoot_grid_kernel<{int(self.desc.geometry)},{pts.value},256,{'true' if trk.value else 'false'},{wpe.value}>"
+
     def eval_points(self, k, w, want_rel=False):
         import torch
         dk, dw = self._dev(k).reshape(-1), self._dev(w).reshape(-1)
@@ -165,6 +173,21 @@ class ShootProblem:
                 continue
             m = min(n.value, rt.capacity)
             return {key: v[:m] for key, v in t.items()}, n.value
+
+    def find_roots_async(self, k, w, D, status, table, count, w_mode=W_PHASE_SPEED, n_bisect=40, tol_percent=1e-3):
+        """es_shoot_find_roots_async: everything enqueued on the context's stream, nothing read back.  `table` is
+        (dict, RootTable) from alloc_root_table, `count` an int32 CUDA tensor of one element that receives the bracket
+        count (it may exceed the capacity: check when reading it).  Returns the full-capacity dict of the table."""
+        dk, dw = self._dev(k).reshape(-1), self._dev(w)
+        nk = dk.numel()
+        nw = dw.shape[-1] if w_mode == W_PER_ROW else dw.numel()
+        t, rt = table
+        assert count.is_cuda and count.numel() == 1 and count.element_size() == 4
+        rc = self.ctx.lib.es_shoot_find_roots_async(self.ctx.handle, self.handle, _lib.ptr(dk), nk, _lib.ptr(dw), nw,
+                                                    w_mode, _lib.ptr(D), _lib.ptr(status), int(n_bisect),
+                                                    float(tol_percent), C.byref(rt), _lib.ptr(count))
+        _lib.check(self.ctx.handle, rc)
+        return t
 
     def find_roots_mixed(self, k, w, w_mode=W_PHASE_SPEED, n_bisect=40, tol_percent=1e-3, capacity=None, table=None):
         """fp32 screening of the grid + fp64 re-evaluation of every unsure point and of both ends of every bracket +

@@ -57,6 +57,13 @@ int es_context_create(int device, void* stream, es_context** out);
 int es_context_destroy(es_context* ctx);
 const char* es_last_error(const es_context* ctx);
 int es_context_synchronize(es_context* ctx);
+/* Measurement aid (bench.py `roofline`): with the timer on, every launch of a grid-march kernel (the fp64 kernel of
+ * es_shoot_eval_grid[_ex], the fp32 screening kernel of es_shoot_find_roots_mixed) is bracketed by HIP events on the
+ * context's stream.  es_context_grid_time synchronises the stream, returns the summed elapsed time and the number of
+ * launches since the last call and forgets them.  The reference has no counterpart (it times whole runs with
+ * time.time(), e.g. Density_cylinder.py:1129). */
+int es_context_grid_timer(es_context* ctx, int enable);
+int es_context_grid_time(es_context* ctx, double* h_total_ms, int* h_launches);
 /* sizeof() of the ABI structs as this library was compiled, for binding self-checks:
  * which = 0 es_slab_analytic_params, 1 es_shoot_desc, 2 es_profiles, 3 es_root_table, 4 es_worker_spec,
  * 5 es_cyl_uniform_params; -1 for an unknown index. */
@@ -167,6 +174,11 @@ int es_shoot_eval_grid_ex(es_context* ctx, const es_problem* prob, const double*
                           const double* d_w, int nw, int w_mode, int flags,
                           double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
 
+/* Measurement aid: the launch shape es_shoot_eval_grid selects for rows of nw frequencies of this problem -- points per
+ * lane, waves per SIMD of the register cap, per-node sign tracking on / off -- i.e. the instantiation
+ * shoot_grid_kernel<family, pts, 256, track, wpe> that bench.py prices against profiles/isa_loop_counts.json. */
+int es_shoot_grid_shape(es_context* ctx, const es_problem* prob, int nw, int* h_pts, int* h_wpe, int* h_track);
+
 /* The same determinant at n arbitrary (k, omega) pairs (one pair per lane, no shared k). */
 int es_shoot_eval_points(es_context* ctx, const es_problem* prob, const double* d_k, const double* d_w, int n,
                          double* d_D, double* d_rel /* may be NULL */, uint8_t* d_status);
@@ -186,8 +198,8 @@ typedef struct es_root_table {
 /* Grid search: brackets = sign changes of D between omega-neighbours of the same row with both ends ES_PT_OK
  * (wavefront shuffle + ballot, ordered compaction: rows outer, omega inner); each bracket is narrowed at least
  * as far as `n_bisect` bisection steps would (the reference's 3-point linspace refinement, e.g. :823-829, run to
- * convergence; executed as rounds of 17-section with 16 lanes per bracket -- 9-section with 8 lanes beyond 32768
- * brackets -- as many as shrink the bracket by 2^n_bisect, always keeping the sign change nearest to the lower end), then polished in fp64 by two regula-falsi steps (the secant through the
+ * convergence; executed as rounds of 17-section with 16 lanes per bracket -- a fixed rule, so that the table of a grid
+ * does not depend on how the grid is tiled over calls or GPUs -- as many as shrink the bracket by 2^n_bisect, always keeping the sign change nearest to the lower end), then polished in fp64 by two regula-falsi steps (the secant through the
  * bracket ends: the Newton-type refinement of the north star, without a derivative of D) and classified with the
  * reference's acceptance rule rel < tol_percent at the last secant point, which is the root reported;
  * [w_lo, w_hi] is the final bracket around it.
@@ -195,6 +207,16 @@ typedef struct es_root_table {
 int es_shoot_find_roots(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                         const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,
                         int n_bisect, double tol_percent, es_root_table* table, int* h_count);
+
+/* es_shoot_find_roots without any host synchronisation (pipelined callers, k-tiles of a multi-GPU run: a 512-row tile
+ * is 3 ms of GPU work, a read-back in the middle of it is a tenth of that).  The bracket count is written to the
+ * caller's device word d_count (it may exceed table->capacity: then only `capacity` brackets were written and refined --
+ * the caller checks when it reads the count, as es_shoot_find_roots does for it).  The refinement launches are sized for
+ * table->capacity and take the count from device memory, so size the table for the data (about twice the expected
+ * count), not for the worst case.  Same table, bit for bit, as es_shoot_find_roots. */
+int es_shoot_find_roots_async(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                              const double* d_w, int nw, int w_mode, const double* d_D, const uint8_t* d_status,
+                              int n_bisect, double tol_percent, es_root_table* table, int32_t* d_count);
 
 /* Mixed-precision grid search (BASELINE.json configs[4]: "fp32 bracket + fp64 refine"; the reference itself is fp64
  * throughout).  Same result as es_shoot_eval_grid + es_shoot_find_roots -- identical bracket set, bit-identical root
@@ -220,6 +242,9 @@ int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const dou
  * (Density_cylinder.py:1155-1168).  Asynchronous on the context's stream. */
 int es_root_table_pack(es_context* ctx, const es_root_table* table, int count, double m,
                        const int64_t* d_rows_global, int cap, double* d_out);
+/* The same with the count in device memory (the d_count of es_shoot_find_roots_async). */
+int es_root_table_pack_async(es_context* ctx, const es_root_table* table, const int32_t* d_count, double m,
+                             const int64_t* d_rows_global, int cap, double* d_out);
 
 /* ========================================================================================================
  * (3) The reference worker itself: kink(wavenumber, kink_ws, kink_ks, freq) / sausage(...) for a batch of

@@ -589,8 +589,9 @@ long port_find_roots(const port_problem* P, const double* k, int nk, const doubl
   long n = count < capacity ? count : capacity;
   int rounds = 0;
   const int polish = 2;
-  /* (LANES+1)-section as the HIP refine_kernel (refine_sections): 17 up to 32768 brackets, 9 beyond */
-  int sections = (n <= 32768) ? 17 : 9;
+  /* (LANES+1)-section as the HIP refine_kernel: the fixed rule kRefineSections = 17 (it must not depend on the bracket
+     count of the call, or a tiled grid would be refined differently from the whole one) */
+  int sections = 17;
   { const char* ev = getenv("ES_REFINE_SECTIONS"); const int v = ev ? atoi(ev) : 0; if (v == 5 || v == 9 || v == 17) sections = v; }
   for (double span = 1.0, need = ldexp(1.0, n_bisect < 1000 ? n_bisect : 1000); span < need; span *= (double)sections) ++rounds;
 #ifdef _OPENMP

@@ -173,3 +173,90 @@ def test_k_tiled_grid_root_set_equals_single_rank():
 def test_fixed_exchange_reports_overflow():
     got = _run_tiled(2, 4)                 # capacity far below the number of brackets of a tile
     assert all(isinstance(got[r][0], str) and "capacity" in got[r][0] for r in range(2))
+
+
+# ---- several units (azimuthal orders / modes) per rank: BASELINE configs[1], [2], [4] in bench.py --------------------
+def _unit_problems():
+    """Two azimuthal orders of a small rotational-flow cylinder (the configs[4] family), C port as compute stand-in."""
+    from eigensolver_amd import equilibrium as q, shooting as s
+    from oracle.port import PortProblem
+    out = []
+    for m in (1, 2):
+        eq = q.CylinderRotation(v_twist=0.1, power=1.0, r_axis=0.001, n_nodes=200)
+        d, prof = s.make_desc(eq, "kink", m)
+        out.append((m, PortProblem({f[0]: getattr(d, f[0]) for f in d._fields_}, prof)))
+    k = np.linspace(0.4, 3.8, 14)
+    W = 0.7 + (np.arange(48) + 0.5) * (0.75 / 48)
+    return out, k, W
+
+
+def _units_step(rank, world, caps):
+    probs, k, W = _unit_problems()
+    rows = D.tile_rows(len(k), rank, world, strided=True)
+    sends, counts = [], []
+    for (m, port), cap in zip(probs, caps):
+        roots, cnt = _tile_step(port, k, W, rows)
+        sends.append(D.pack_fixed(roots, cnt, m, torch.as_tensor(rows), cap))
+        counts.append(cnt)
+    return D.concat_fixed(sends), counts
+
+
+def _worker_units(rank, world, port_no, caps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port_no)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    send, counts = _units_step(rank, world, caps)
+    cap_dyn = D.exchange_capacity(max(counts))               # one all_reduce(MAX): identical on every rank
+    buf = D.gather_fixed(send, world)
+    try:
+        rec, per = D.merge_units(buf, caps)
+        q.put((rank, rec, per, cap_dyn))
+    except OverflowError as e:
+        q.put((rank, str(e), None, cap_dyn))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_units(world, caps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_no = _free_port()
+    procs = [ctx.Process(target=_worker_units, args=(r, world, port_no, caps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, rec, per, cap_dyn = q.get(timeout=300)
+        got[r] = (rec, per, cap_dyn)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_units_tiled_over_ranks_merge_to_the_single_rank_table():
+    """(m x k-row) tiling of bench.py --workload config1/2/4: every rank owns rows r, r + N, ... of EVERY unit, the
+    units' fixed-capacity tables travel in ONE all-gather, and the merged table is the N = 1 table record for record
+    (units outer, rows next, omega inner); the exchange capacity comes from the data and is the same on every rank."""
+    caps = [64, 128]
+    send, counts = _units_step(0, 1, caps)
+    single, per = D.merge_units(D.gather_fixed(send, 1), caps)
+    assert per == [counts] and sum(counts) == single.shape[0] and min(counts) > 3
+    assert np.all(np.diff(single[:, 2]) >= 0)                     # units in order
+    for m in (1.0, 2.0):
+        assert np.all(np.diff(single[single[:, 2] == m][:, 5]) >= 0)   # rows in order inside a unit
+    for world in (2, 3):
+        got = _run_units(world, caps)
+        dyn = {got[r][2] for r in range(world)}
+        assert len(dyn) == 1 and dyn.pop() >= 64
+        for r in range(world):
+            rec, per_rank, _ = got[r]
+            assert np.array_equal(rec, single), (world, r)
+            assert [sum(p[i] for p in per_rank) for i in range(2)] == counts
+    got = _run_units(2, [2, 128])                                 # first unit overflows its slot
+    assert all(isinstance(got[r][0], str) and "capacity" in got[r][0] for r in range(2))
+
+
+def test_exchange_capacity_is_a_power_of_two_twice_the_count():
+    assert D.exchange_capacity(0) == 64 and D.exchange_capacity(32) == 64 and D.exchange_capacity(33) == 128
+    assert D.exchange_capacity(820) == 2048 and D.exchange_capacity(6561) == 16384
