@@ -498,7 +498,7 @@ def test_grid_shapes_bit_identical(es_ctx, name, monkeypatch):
         for probe_nw in (64, 128, 192, 256, 384, 512, 1024, 4096):
             _lib.check(es_ctx.handle, es_ctx.lib.es_shoot_grid_shape(es_ctx.handle, gp.handle, probe_nw, C.byref(pts), C.byref(wpe), C.byref(trk)))
             wpes[pts.value] = wpe.value
-        assert 4 in wpes
+        assert len(wpes) >= 2, wpes
         out = []
         for p_, w_ in sorted(wpes.items()):
             monkeypatch.setenv("ES_GRID_SHAPE", f"{p_},{w_}")
