@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void bracket_emit_kernel(const double* __restr
 // ES_REFINE_SECTIONS = 5 / 9 / 17 in the environment selects another rule for the whole process (tuning aid, honoured by
 // the port); the port mirrors the default.
 constexpr int kRefineSections = 17;
-constexpr int kSharedMin = 2048;   // brackets from which the wave-shared node entries are used (untwisted cylinder)
+constexpr int kSharedMin = 0;      // brackets from which the wave-shared node entries are used (untwisted cylinder): always
 
 // Workgroups of 4 waves share ONE LDS staging of the (k-independent) base table: 3.6 KB of LDS per wave instead of 14.4,
 // so occupancy is no longer LDS-bound and the compiler aims for the register footprint of the point kernel -- which is
@@ -1064,12 +1064,11 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   // the ends of the narrowed bracket from one kernel to the other)
   const int np = (ES_REFINE_POLISH > 0 && rounds > 0) ? -1 : ES_REFINE_POLISH;
   // 17-section of the untwisted cylinder with np < 0 (sections only): node entries shared inside the wave, 32 steps per
-  // chunk (14.6 KB of LDS per wave).  Bit-identical to the per-lane entries, so the choice may follow the bracket count:
-  // the 58 KB workgroups pay off when the launch is several waves per SIMD deep (N = 1 bench: 6 561 brackets) and lose
-  // on the few hundred brackets of a k-tile, where they wait for LDS beside the grid workgroups of the next step
-  // (ES_REFINE_SHARED_MIN, default kSharedMin; measured in profiles/README.md, round 3).  The twisted family (16
-  // entries per node: 17 KB per wave at 16 steps per chunk, one workgroup per CU) lost 7 % on configs[4] and keeps
-  // per-lane entries.
+  // chunk (14.6 KB of LDS per wave).  Bit-identical to the per-lane entries, so the choice could follow the bracket count
+  // (ES_REFINE_SHARED_MIN); measured in round 3 with the count on the device (same box, tile of an E-GPU run, ms per
+  // step shared / per-lane: E = 1 22.05 / 22.29, E = 2 11.35 / 11.28, E = 4 5.85 / 5.98, E = 8 3.19 / 3.29): no
+  // crossover worth a rule, the shared form is the default at every count.  The twisted family (16 entries per node:
+  // 17 KB per wave at 16 steps per chunk, one workgroup per CU) lost 7 % on configs[4] and keeps per-lane entries.
   constexpr int CHR = (FAM == FAM_CYL0) ? 32 : 0;
   int shared_min = kSharedMin;
   if (const char* ev = getenv("ES_REFINE_SHARED_MIN")) shared_min = atoi(ev);

@@ -115,10 +115,10 @@ __device__ __forceinline__ void make_entry(const double* b, const KScal& s, doub
     e[6] = -(Bq * (e[2] * e[2]));
     if (SCALED) { e[3] *= s.h2; e[4] *= s.h2; e[5] *= s.h2; e[6] *= s.h2; }
   } else if (FAM == FAM_CYLT) {
-    const double kb = b[CT_MB] + s.k * b[CT_BZ];               // m B_phi/r + k B_z
-    const double wA = b[CT_MB] + s.k * b[CT_BA];               // as written in the reference (CF:581)
+    const double kb = fma(s.k, b[CT_BZ], b[CT_MB]);            // m B_phi/r + k B_z
+    const double wA = fma(s.k, b[CT_BA], b[CT_MB]);            // as written in the reference (CF:581)
     const double wA2 = wA * wA;
-    e[0] = b[CT_MV] + s.k * b[CT_VZ];                          // shift: m v_phi/r + k v_z
+    e[0] = fma(s.k, b[CT_VZ], b[CT_MV]);                       // shift: m v_phi/r + k v_z
     e[1] = wA2;
     e[2] = wA2 * b[CT_Q];
     e[3] = b[CT_E3];                                           // rho S
@@ -208,18 +208,21 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     C.n22 = e[4];                                        // -B, added after the division (coef_finish)
     C.den = t1 * t2;
   } else if (FAM == FAM_CYLT) {
+    // 23 fp64 instructions per node (33 until round 3, when every product-sum below was a multiply and an add): the sums
+    // are explicit fused multiply-adds, grouped as in the fp32 screening kernel (coef_pre_f32); t2 T is formed once
     const double Om = w - e[0];
     const double Om2 = Om * Om;
     const double t1 = Om2 - e[1];
     const double t2 = Om2 - e[2];
     if (TRACK) { st.add(0, t1); st.add(1, t2); }
     const double D = e[3] * t1 * t2;
-    const double Q = Om2 * e[6] - t1 * e[5] + Om * e[7];
-    const double T = e[8] + e[9] * Om;
+    const double Q = fma(Om, e[7], fma(Om2, e[6], -(t1 * e[5])));
+    const double T = fma(e[9], Om, e[8]);
     const double OmP = (P.c1_power == 2) ? Om2 : Om;
-    const double C1 = Q * OmP - e[10] * t2 * T;
-    const double C2 = Om2 * Om2 - e[11] * t2;
-    const double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
+    const double t2T = t2 * T;
+    const double C1 = fma(Q, OmP, -(e[10] * t2T));
+    const double C2 = fma(Om2, Om2, -(e[11] * t2));
+    const double C3 = fma(D, fma(e[4], t1, e[12]), fma(Q, Q, -((e[13] * t2T) * T)));
     if (TRACK) { st.add(2, C3 * D); }   // F = r D / C3 changes sign where C3 does
     C.n11 = -C1;                                         // all four entries /den
     C.n22 = C1;

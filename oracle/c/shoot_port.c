@@ -267,9 +267,9 @@ static void make_entry(const port_problem* P, int pt, const kscal* s, double* e)
     case 1: {
       double r = b[0], invr = b[1], rho = b[2], S = b[3];
       double Bphi = b[7] * r, vphi = b[8] * r;
-      double kb = s->m * b[7] + s->k * b[6];
-      double wA = s->m * b[7] + s->k * b[5], wA2 = wA * wA, invr2 = invr * invr;
-      e[0] = s->m * b[8] + s->k * b[9]; e[1] = wA2; e[2] = wA2 * b[4]; e[3] = rho * S; e[4] = rho;
+      double kb = fma(s->k, b[6], s->m * b[7]);
+      double wA = fma(s->k, b[5], s->m * b[7]), wA2 = wA * wA, invr2 = invr * invr;
+      e[0] = fma(s->k, b[9], s->m * b[8]); e[1] = wA2; e[2] = wA2 * b[4]; e[3] = rho * S; e[4] = rho;
       e[5] = rho * vphi * vphi * invr; e[6] = 2.0 * Bphi * Bphi * invr; e[7] = 2.0 * Bphi * vphi * kb * invr;
       e[8] = kb * Bphi; e[9] = rho * vphi; e[10] = 2.0 * s->m * S * invr2; e[11] = S * (s->m2 * invr2 + s->k2);
       e[12] = b[10]; e[13] = 4.0 * S * invr2; e[14] = r; e[15] = invr;
@@ -300,13 +300,15 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
     case 1: {
       double Om = w - e[0], Om2 = Om * Om, t1 = Om2 - e[1], t2 = Om2 - e[2];
       st_add(st, 0, t1); st_add(st, 1, t2);
+      /* product-sums as explicit fused multiply-adds, grouped as in the HIP coef_pre<FAM_CYLT> (round 3) */
       double D = e[3] * t1 * t2;
-      double Q = Om2 * e[6] - t1 * e[5] + Om * e[7];
-      double T = e[8] + e[9] * Om;
+      double Q = fma(Om, e[7], fma(Om2, e[6], -(t1 * e[5])));
+      double T = fma(e[9], Om, e[8]);
       double OmP = (P->c1_power == 2) ? Om2 : Om;
-      double C1 = Q * OmP - e[10] * t2 * T;
-      double C2 = Om2 * Om2 - e[11] * t2;
-      double C3 = D * (e[4] * t1 + e[12]) + Q * Q - e[13] * t2 * T * T;
+      double t2T = t2 * T;
+      double C1 = fma(Q, OmP, -(e[10] * t2T));
+      double C2 = fma(Om2, Om2, -(e[11] * t2));
+      double C3 = fma(D, fma(e[4], t1, e[12]), fma(Q, Q, -((e[13] * t2T) * T)));
       st_add(st, 2, C3 * D);
       C->n11 = -C1; C->n22 = C1; C->n12 = C3 * e[15]; C->n21 = -(e[14] * C2); C->den = D;
     } break;
