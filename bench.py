@@ -13,7 +13,8 @@ detection (wave shuffle + ballot), 9-section + secant refinement, ordered root c
 The kernels run on torch's current stream of the device (the stream the es_context is created with), so the
 torch.cuda.Event pairs around the grid launch time exactly that kernel.
 
-Consecutive steps are software-pipelined over --streams S (default 2) library contexts = HIP streams, one host thread
+Consecutive steps are software-pipelined over --streams S (default 3; the 512-row tile of an 8-GPU run: 4.11 / 3.07 / 2.88 / 3.03 ms
+per step with 1 / 2 / 3 / 4, the whole grid 20.8 ms with 2 or 3) library contexts = HIP streams, one host thread
 each: grid launches stay serialised (each has the whole chip), the latency-bound bracket refinement of step i (about
 one wave per SIMD) overlaps the grid launch of step i + 1; collectives are issued by the main thread in step order.
 
@@ -272,9 +273,9 @@ def main():
                          "evaluates every point; the skip mode is then measured after the timed region and reported "
                          "under config.skip_continuum_mode")
     ap.add_argument("--dump-roots", default=None, help="write the merged root table of the last step to this .npy")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="software pipelining of consecutive steps: S library contexts (HIP streams), each driven by its own "
-                         "host thread; the latency-bound refinement of step i overlaps the grid launch of step i + 1")
+                         "host thread; the latency-bound refinement of step i overlaps the grid launches of steps i + 1, i + 2")
     ap.add_argument("--no-extra-mode", action="store_true",
                     help="do not measure the other continuum mode after the timed region (profiling runs: keeps the "
                          "per-kernel counters of one mode apart)")
@@ -560,7 +561,7 @@ def main():
                          "evals_per_launch": launch_evals, "avg_launch_ms": grid_ms,
                          "avg_launch_ms_unshared": (float(np.mean(unshared)) if unshared else None),
                          "launch_note": "avg_launch_ms: HIP events around every grid launch of the timed region; with "
-                                        "--streams 2 the previous step's refinement shares the chip with it. "
+                                        "pipelined streams the previous steps' refinement shares the chip with it. "
                                         "avg_launch_ms_unshared: the same launch alone on a busy chip (back-to-back launches before the timed region)",
                          "note": "fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64"},
             "valu_fp64": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

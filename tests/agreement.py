@@ -192,13 +192,16 @@ def classify_call(solver, key, call, port=None):
     return out
 
 
-def classify_fixture(kind, name, solver=None):
+def classify_fixture(kind, name, solver=None, conv=False):
+    """conv=True: the *_conv fixture of the same name (reference run with its unconverged fsolve calls re-solved to
+    convergence on its own objective); the "fsolve" category is then left to the evaluations even the re-solve could not
+    converge (a non-finite objective)."""
     from tests import refcases
     key, factory = refcases.solver_factories()[name]
     solver = solver if solver is not None else factory()
     ports = {}
     res = []
-    for call in refcases.load_calls(kind, name):
+    for call in refcases.load_calls(kind, name, conv=conv):
         if call["fn"] not in ports:
             ports[call["fn"]] = port_for(solver, call["fn"])
         res.append(classify_call(solver, key, call, ports[call["fn"]]))

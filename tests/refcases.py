@@ -36,12 +36,16 @@ def solver_factories():
     }
 
 
-def trace_names():
-    return sorted(f[6:-5] for f in os.listdir(G) if f.startswith("trace_") and f.endswith(".json"))
+def trace_names(conv=False):
+    """Worker-trace fixtures; conv=True: the second set (trace_*_conv.json, tools/gen_golden.py --converge), in which the
+    reference's unconverged fsolve calls were re-solved to convergence on its own objective."""
+    names = sorted(f[6:-5] for f in os.listdir(G) if f.startswith("trace_") and f.endswith(".json"))
+    return [n[:-5] for n in names if n.endswith("_conv")] if conv else [n for n in names if not n.endswith("_conv")]
 
 
-def rootset_names():
-    return sorted(f[6:-5] for f in os.listdir(G) if f.startswith("roots_") and f.endswith(".json"))
+def rootset_names(conv=False):
+    names = sorted(f[6:-5] for f in os.listdir(G) if f.startswith("roots_") and f.endswith(".json"))
+    return [n[:-5] for n in names if n.endswith("_conv")] if conv else [n for n in names if not n.endswith("_conv")]
 
 
 def call_freq(c):
@@ -51,11 +55,17 @@ def call_freq(c):
     return np.linspace(c["band"][0] * c["k"], c["band"][1] * c["k"], c["n"])
 
 
-def load_calls(kind, name):
+def load_calls(kind, name, conv=False):
     """Uniform view of a fixture: list of dicts {fn, k, freq, roots_w, n_fsolve_fail, evals}, evals = list of
-    (where, omega, d, ext_value, ext_slope, ier) in the order the reference evaluated them (None if not recorded)."""
+    (where, omega, d, ext_value, ext_slope, ier) in the order the reference evaluated them (None if not recorded).
+    conv=True reads the *_conv fixture; there `ier` is 1 for an evaluation whose slope is converged -- by fsolve itself
+    or by the harness's re-solve of the reference's own objective -- and fsolve's flag otherwise."""
+    sfx = "_conv" if conv else ""
+
+    def eff(ier, cv):
+        return 1 if (conv and cv == 1) else ier
     if kind == "trace":
-        tr = json.load(open(os.path.join(G, f"trace_{name}.json")))
+        tr = json.load(open(os.path.join(G, f"trace_{name}{sfx}.json")))
         out = []
         for c in tr["calls"]:
             evs = []
@@ -65,12 +75,12 @@ def load_calls(kind, name):
                 ext = e["ext_end"]
                 if len(ext) == 4:
                     ext = [ext[0], ext[2]]
-                evs.append((e["where"], e["omega"], e["d"], ext[0], ext[1], e["ier"]))
+                evs.append((e["where"], e["omega"], e["d"], ext[0], ext[1], eff(e["ier"], e.get("conv"))))
             out.append({"fn": c["fn"], "k": c["k"], "freq": np.array(c["freq"]), "roots_w": c["roots_w"],
-                        "n_fsolve_fail": sum(1 for e in c["evals"] if e["ier"] != 1), "evals": evs})
+                        "n_fsolve_fail": sum(1 for e in c["evals"] if eff(e["ier"], e.get("conv")) != 1), "evals": evs})
         return out
-    rs = json.load(open(os.path.join(G, f"roots_{name}.json")))
-    ev_path = os.path.join(G, f"roots_{name}_evals.npz")
+    rs = json.load(open(os.path.join(G, f"roots_{name}{sfx}.json")))
+    ev_path = os.path.join(G, f"roots_{name}{sfx}_evals.npz")
     cols = None
     if os.path.exists(ev_path):
         with np.load(ev_path) as z:
@@ -85,7 +95,8 @@ def load_calls(kind, name):
                 if np.isnan(cols["omega"][i]) or cols["where"][i] < 0:
                     continue
                 evs.append(("loop" if cols["where"][i] == 1 else "main", float(cols["omega"][i]), float(cols["d"][i]),
-                            float(cols["ext_value"][i]), float(cols["ext_slope"][i]), int(cols["ier"][i])))
+                            float(cols["ext_value"][i]), float(cols["ext_slope"][i]),
+                            eff(int(cols["ier"][i]), int(cols["conv"][i]) if "conv" in cols else None)))
         out.append({"fn": c["fn"], "k": c["k"], "freq": call_freq(c), "roots_w": c["roots_w"],
-                    "n_fsolve_fail": c["n_fsolve_fail"], "evals": evs})
+                    "n_fsolve_fail": c.get("n_unconverged", c["n_fsolve_fail"]) if conv else c["n_fsolve_fail"], "evals": evs})
     return out

@@ -119,8 +119,12 @@ def make_freq(spec, k):
     return np.linspace(spec[1], spec[2], spec[3])
 
 
+SUFFIX = ""          # "_conv" with --converge
+
+
 def gen_case(name):
     import ref_harness as H
+    H.CONVERGE = bool(SUFFIX)
     key, repl, calls = CASES[name]
     t0 = time.time()
     ns = H.load_worker_module(key, repl)
@@ -137,12 +141,16 @@ def gen_case(name):
                "linspace3": [[e[1], e[2]] for e in tr if e[0] == "linspace3"],
                "evals": [{"omega": e["omega"], "d": e["d"], "ext_end": e["ext_end"], "ier": e["ier"],
                           "where": e["where"], "int_y0": e.get("int_y0"), "int_end": e.get("int_end"),
-                          "slope": e.get("slope")} for e in evs]}
+                          "slope": e.get("slope"), **({"conv": e.get("conv")} if SUFFIX else {})} for e in evs]}
         out["calls"].append(rec)
     out["seconds"] = round(time.time() - t0, 1)
-    with open(os.path.join(GOLD, f"trace_{name}.json"), "w") as f:
+    if SUFFIX:
+        out["converged_mode"] = ("fsolve calls with ier != 1 re-solved to convergence on the reference's own objective "
+                                 "(tools/ref_harness.py CONVERGE); `ier` is the flag fsolve returned, `conv` = 1 if the slope "
+                                 "the worker continued with is converged")
+    with open(os.path.join(GOLD, f"trace_{name}{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=0)
-    return f"trace_{name}.json ({out['seconds']} s, {sum(len(c['evals']) for c in out['calls'])} evals)"
+    return f"trace_{name}{SUFFIX}.json ({out['seconds']} s, {sum(len(c['evals']) for c in out['calls'])} evals)"
 
 
 def _run(name):
@@ -257,21 +265,25 @@ def gen_rootset(name):
     0 = main loop / 1 = inside locate_*) -- what tests/test_reference_agreement.py needs to explain every call whose
     root list differs."""
     import ref_harness as H
+    H.CONVERGE = bool(SUFFIX)
     key, repl, ks, bands, n, modes = ROOTSETS[name]
     t0 = time.time()
     ns = H.load_worker_module(key, repl)
     init = H.snapshot_initial(ns)
     out = {"case": name, "file": H.FILES[key], "replacements": repl, "calls": []}
-    cols = {c: [] for c in ("call", "omega", "d", "ext_value", "ext_slope", "ier", "where")}
+    cols = {c: [] for c in ("call", "omega", "d", "ext_value", "ext_slope", "ier", "where", "conv")}
     for k in ks:
         for b in bands:
             freq = rootset_freq(ns, b, float(k), n)
             for fn in modes:
                 rw, rk, tr = H.run_worker(ns, init, fn, float(k), freq)
                 iers = [e[3] for e in tr if e[0] == "fsolve"]
+                unconv = [e for e in tr if e[0] == "fsolve" and not (e[4] if len(e) > 4 else e[3] == 1)]
                 evs = H.evaluations(tr)
                 rec = {"fn": fn, "k": float(k), "n": len(freq), "roots_w": rw, "n_evals": len(evs),
                        "n_fsolve_fail": int(sum(1 for i in iers if i != 1))}
+                if SUFFIX:
+                    rec["n_unconverged"] = len(unconv)
                 if isinstance(b, str):
                     rec["freq_kind"] = b
                     rec["freq"] = [float(x) for x in freq]
@@ -288,29 +300,37 @@ def gen_rootset(name):
                     cols["ext_value"].append(ext[0])
                     cols["ext_slope"].append(ext[1])
                     cols["ier"].append(-1 if e["ier"] is None else e["ier"])
+                    cols["conv"].append(-1 if e.get("conv") is None else e["conv"])
                     cols["where"].append(1 if e["where"] == "loop" else (0 if e["where"] == "main" else -1))
                 out["calls"].append(rec)
     out["seconds"] = round(time.time() - t0, 1)
     for k_ in ("xi_tol", "p_tol", "P_tol"):
         if k_ in ns:
             out[k_] = float(ns[k_])
-    with open(os.path.join(GOLD, f"roots_{name}.json"), "w") as f:
+    with open(os.path.join(GOLD, f"roots_{name}{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=0)
-    np.savez_compressed(os.path.join(GOLD, f"roots_{name}_evals.npz"),
+    np.savez_compressed(os.path.join(GOLD, f"roots_{name}{SUFFIX}_evals.npz"), conv=np.array(cols["conv"], dtype=np.int8),
                         call=np.array(cols["call"], dtype=np.int32), omega=np.array(cols["omega"]),
                         d=np.array(cols["d"]), ext_value=np.array(cols["ext_value"]),
                         ext_slope=np.array(cols["ext_slope"]), ier=np.array(cols["ier"], dtype=np.int8),
                         where=np.array(cols["where"], dtype=np.int8))
-    return f"roots_{name}.json ({out['seconds']} s, {sum(len(c['roots_w']) for c in out['calls'])} roots, {len(cols['call'])} evals)"
+    return f"roots_{name}{SUFFIX}.json ({out['seconds']} s, {sum(len(c['roots_w']) for c in out['calls'])} roots, {len(cols['call'])} evals)"
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--jobs", type=int, default=6)
+    ap.add_argument("--converge", action="store_true",
+                    help="second fixture set (*_conv*): fsolve calls the reference leaves unconverged (ier != 1) are re-solved "
+                         "to convergence on the reference's own objective; worker traces and root sets only")
     a = ap.parse_args()
+    if a.converge:
+        SUFFIX = "_conv"
     os.makedirs(GOLD, exist_ok=True)
     names = ["slab_analytic", "equilibria"] + list(CASES) + ["roots:" + n for n in ROOTSETS]
+    if a.converge:
+        names = [n for n in names if n not in ("slab_analytic", "equilibria")]
     if a.only:
         names = [n for n in names if n in a.only.split(",")]
     import multiprocessing as mp

@@ -2,7 +2,10 @@
 C port, tests/agreement.py) and write tests/golden/agreement_table.json, the committed per-call category table that
 tests/test_reference_agreement.py reproduces; prints the markdown table of DESIGN.md section 6.
 
-    python tools/report_call_classification.py [--no-write] [-v]
+    python tools/report_call_classification.py [--no-write] [-v] [--converged]
+
+--converged: the second fixture set (tests/golden/*_conv*, tools/gen_golden.py --converge: the reference run again with
+its unconverged fsolve calls re-solved to convergence on its own objective) -> tests/golden/agreement_table_conv.json.
 """
 import json
 import os
@@ -19,11 +22,12 @@ CATS = ["identical", "fsolve", "singular", "exterior", "interior_noise", "unexpl
 
 def main():
     verbose = "-v" in sys.argv
+    conv = "--converged" in sys.argv
     table, rows, tot = {}, [], {}
-    for kind, names in (("trace", R.trace_names()), ("roots", R.rootset_names())):
+    for kind, names in (("trace", R.trace_names(conv)), ("roots", R.rootset_names(conv))):
         for name in names:
             t = time.time()
-            res = A.classify_fixture(kind, name)
+            res = A.classify_fixture(kind, name, conv=conv)
             sm = A.summarize(res)
             table[f"{kind}:{name}"] = [r["category"] for r in res]
             rows.append((kind, name, R.solver_factories()[name][0], len(res), sm, sum(r["same_roots"] for r in res)))
@@ -45,7 +49,7 @@ def main():
     bad = tot.get("unexplained", 0) + tot.get("no_trace", 0)
     print(f"\nunexplained: {tot.get('unexplained', 0)}, without evaluation records: {tot.get('no_trace', 0)}")
     if "--no-write" not in sys.argv:
-        with open(os.path.join(R.G, "agreement_table.json"), "w") as f:
+        with open(os.path.join(R.G, "agreement_table_conv.json" if conv else "agreement_table.json"), "w") as f:
             json.dump(table, f, indent=0, sort_keys=True)
     return 1 if bad else 0
 
