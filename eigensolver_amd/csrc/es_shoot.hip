@@ -957,6 +957,7 @@ constexpr bool shape_built() {
   return true;
 #else
   if (TRACK && fam_has_bands<FAM>()) return WPE == 2;
+  if (FAM == FAM_CYL0 && PTS == 4 && WPE == 2) return true;   // A/B aid for the headline shape (ES_GRID_SHAPE=4,2: 175 VGPRs, no spill)
   return ShapeTable<FAM>::wpe[PTS] == WPE;
 #endif
 }

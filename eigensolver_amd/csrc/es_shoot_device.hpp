@@ -252,12 +252,13 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     const double St = P.S_i * t;
     const double G = fma(St, t, s.k4c);
     const double X = Om * n1;
+    const double OX = Om * X;                            // n1 Om^2: shared by the numerator of coeff and the denominator
     const double g2 = e[3] * G;                          // 2 k U' G
     C.n11 = 0.0;
     C.n12 = 1.0;
     C.n22 = g2 * Om;                                     // -D                          /den
-    C.n21 = -(fma(e[2], St * X, (n1 * n3) * (n1 * Om2)) - g2 * e[1]);   // -coeff       /den
-    C.den = St * (Om * X);
+    C.n21 = -fma(e[2], St * X, fma(-g2, e[1], (n1 * n3) * OX));         // -coeff       /den
+    C.den = St * OX;
   }
 }
 

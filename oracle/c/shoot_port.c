@@ -322,11 +322,11 @@ static void coef_pre(const port_problem* P, const double* e, const kscal* s, dou
       if (st) { st_add(st, 0, n1); st_add(st, 1, t); st_add(st, 2, n3); st_add(st, 3, Om); }
       /* m0, D, coeff of SF-G:416-427 over the common denominator S t Om^2 n1 (G = S t^2 + k^4 cT^2 c^2):
          D = -2 k U' G Om / den,  coeff = (k U'' S t Om n1 - 2 (k U')^2 G + n1^2 n3 Om^2) / den */
-      double St = P->S_i * t, G = fma(St, t, s->k4c), X = Om * n1, g2 = e[3] * G;
+      double St = P->S_i * t, G = fma(St, t, s->k4c), X = Om * n1, OX = Om * X, g2 = e[3] * G;
       C->n11 = 0.0; C->n12 = 1.0;
       C->n22 = g2 * Om;
-      C->n21 = -(fma(e[2], St * X, (n1 * n3) * (n1 * Om2)) - g2 * e[1]);
-      C->den = St * (Om * X);
+      C->n21 = -fma(e[2], St * X, fma(-g2, e[1], (n1 * n3) * OX));
+      C->den = St * OX;
     }
   }
 }

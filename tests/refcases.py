@@ -63,7 +63,8 @@ def load_calls(kind, name, conv=False):
     sfx = "_conv" if conv else ""
 
     def eff(ier, cv):
-        return 1 if (conv and cv == 1) else ier
+        # conv codes of tools/ref_harness.py: 1 converged, 4 converged to the noise floor of the reference's own objective
+        return 1 if (conv and cv in (1, 4)) else ier
     if kind == "trace":
         tr = json.load(open(os.path.join(G, f"trace_{name}{sfx}.json")))
         out = []

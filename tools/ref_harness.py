@@ -89,37 +89,64 @@ def _odeint(func, y0, t, *a, **kw):
 # (*_conv*) answer "what does the reference compute when its solver does what the author intended", so that a call whose
 # decisions differ can no longer be excused by ier != 1.
 CONVERGE = False
+LSODA_ATOL = 1.5e-8          # scipy.integrate.odeint default (the scripts pass none)
 
 
 def _resolve_affine(func, x_fail, x0, args):
+    """Root of the reference's objective `func`, which is affine in the slope up to the noise of its LSODA solves.
+    The derivative is taken ONCE from two abscissae far enough apart that the difference of the objective stands 1000 x above
+    LSODA's absolute tolerance (the objective of the slab scripts is ~1e-8 in size near its root: two nearby points would
+    divide noise by noise); then Newton steps with that fixed derivative.  Returns (slope, objective calls, code): 1 the step
+    fell below 1e-5 relative; 4 below 4 atol / |f'|, the accuracy to which LSODA's absolute tolerance defines the root at all;
+    0 neither after five steps; 2 the objective does not depend on the slope; 3 non-finite objective."""
     def f(s):
         return float(np.real(np.ravel(func(np.array([s], dtype=float), *args))[0]))
     sa = float(np.ravel(x0)[0])
-    sb = float(x_fail)
-    if not np.isfinite(sb) or sb == sa:
-        sb = sa * 1.5 + 1.0
-    fa, fb = f(sa), f(sb)
-    n = 2
+    fa = f(sa)
+    n = 1
+    if not np.isfinite(fa):
+        return sa, n, 3
+    step = max(abs(sa), abs(float(x_fail)) if np.isfinite(x_fail) else 0.0, 1e-6)
+    d = None
     for _ in range(8):
-        if not (np.isfinite(fa) and np.isfinite(fb)) or fa == fb:
-            return sb, n, False
-        sn = sb - fb * (sb - sa) / (fb - fa)
-        fn = f(sn)
+        sb = sa + step
+        fb = f(sb)
         n += 1
-        if abs(sn - sb) <= 1e-9 * max(abs(sn), 1e-300):
-            return sn, n, bool(np.isfinite(fn))
-        sa, fa, sb, fb = sb, fb, sn, fn
-    return sb, n, False
+        if not np.isfinite(fb):
+            return sa, n, 3
+        if abs(fb - fa) > 1e3 * LSODA_ATOL:
+            d = (fb - fa) / (sb - sa)
+            break
+        step *= 100.0
+    if d is None:
+        return sa, n, 2
+    s1 = sa - fa / d
+    for _ in range(5):
+        f1 = f(s1)
+        n += 1
+        if not np.isfinite(f1):
+            return s1, n, 3
+        sn = s1 - f1 / d
+        if abs(sn - s1) <= 1e-5 * max(abs(sn), 1e-300):
+            return sn, n, 1
+        if abs(sn - s1) <= 4.0 * LSODA_ATOL / abs(d):
+            return sn, n, 4
+        s1 = sn
+    return s1, n, 0
 
 
 def _fsolve(func, x0, *a, **kw):
     x, info, ier, msg = scipy.optimize.fsolve(func, x0, *a, full_output=True, **kw)
     if CONVERGE and ier != 1 and np.size(x) == 1:
         try:
-            xs, n_extra, ok = _resolve_affine(func, x[0], x0, kw.get("args", ()))
+            xs, n_extra, code = _resolve_affine(func, x[0], x0, kw.get("args", ()))
         except Exception:
-            xs, n_extra, ok = float(x[0]), 0, False
-        TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(xs if ok else x[0]), int(ier), 1 if ok else 0, int(n_extra)))
+            xs, n_extra, code = float(x[0]), 0, 3
+        ok = code in (1, 4)
+        # conv: 1 converged to 1e-5 relative; 4 converged to the noise floor of the objective (LSODA's absolute tolerance);
+        # 0 still moving after the iterations; 2 the objective does not depend on the slope at all (the reference's
+        # interior solve fails at once); 3 non-finite objective
+        TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(xs if ok else x[0]), int(ier), int(code), int(n_extra)))
         if ok:
             return np.array([xs], dtype=float)
         return x

@@ -15,7 +15,7 @@ a = np.load("$R/gpurun_out/roots_n1.npy"); b = np.load("$R/gpurun_out/roots_n$N.
 j = json.loads(open("$R/gpurun_out/rehearse_n$N.json").read().strip().splitlines()[-1])
 same = a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
 print(f"N=$N: {b.shape[0]} gathered records, identical to N=1: {same}; value {j['value']:.3e} {j['unit']}, "
-      f"{j['ms_per_step']:.2f} ms/step, scaling {j['scaling']}, rows/GPU {j['config']['k_rows_per_gpu']}")
+      f"{j['ms_per_step']:.2f} ms/step, scaling {j['scaling']}, rows/GPU {j['config'].get('k_rows_per_gpu', j['config'].get('k_rows_per_gpu_per_unit'))}")
 assert same
 PY
 done
