@@ -55,7 +55,7 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
   // ds_read2_b64 from its own base register: 7 address moves per loop iteration, 2 % of its VALU instructions)
   constexpr int LSTRIDE = 2 * CH + 2;
   // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
-  constexpr bool PAIR = (FAM == FAM_CYL0) && (PTS == 4) && !TRACK;
+  constexpr bool PAIR = (FAM == FAM_CYL0) && !TRACK;
   // register-capped instantiations (WPE != 0) park the exterior results in LDS during the march instead of letting
   // the compiler spill them to scratch (HBM): 4 doubles per point, lane-contiguous (conflict-free)
   constexpr bool STASH = (WPE != 0);

@@ -75,12 +75,13 @@ class RefReplay:
                 raise KeyError(("the state machine asked for a point the reference never evaluated", k, w))
             return OW.ST_LEAKY, float("nan"), float("nan"), float("nan")
         rec = q.pop(0) if len(q) > 1 else q[0]
-        where, _, d, ev, es, ier = rec
+        where, _, d, ev, es, ier = rec[:6]
+        code = rec[6] if len(rec) > 6 else None
         A = abs(ev)
         stx, d_mix, rel_mix, outer_mix, inner_mix = self.port.eval_one(k, w, w_cst, ext=(ev, es))
         outer = outer_mix                      # cst * slope / A with the reference's slope
         dn = d / A
-        self.used.append({"w": w, "ier": ier, "A": A, "d_mix": d_mix, "rel_mix": rel_mix, "outer_mix": outer_mix,
+        self.used.append({"w": w, "ier": ier, "conv": code, "A": A, "d_mix": d_mix, "rel_mix": rel_mix, "outer_mix": outer_mix,
                           "inner_mix": inner_mix, "st_mix": stx})
         return OW.ST_OK, dn, outer, outer - dn
 
@@ -136,6 +137,14 @@ def classify_call(solver, key, call, port=None):
     # 1. non-converged fsolve in the reference
     if u["ier"] != 1 or (sign_matters and up is not None and up["ier"] != 1):
         out["category"] = "fsolve"
+        # converged-fixture set: WHY the reference's own objective could not be solved at that evaluation (conv code of
+        # tools/ref_harness.py), and how far its mismatch is from what our interior gives behind its own exterior
+        bad = u if u["ier"] != 1 else up
+        out["fsolve_reason"] = {0: "no root within the noise of its objective (next to a pole of D the objective's slope vanishes)",
+                                2: "its objective does not depend on the slope (the interior LSODA solve fails at once)",
+                                3: "its objective is non-finite", None: "ier != 1 (first fixture set)"}.get(bad["conv"], str(bad["conv"]))
+        sc = max(abs(bad["outer_mix"]), abs(bad["inner_mix"]))
+        out["fsolve_pole"] = bool(abs(bad["outer_mix"]) <= max(NOISE_FLOOR, 40 * ATOL / bad["A"]) * abs(bad["inner_mix"])) if sc > 0 else None
         return out
     # 2. singular point (ours flags it)
     bp = ours.log[pi] if pi is not None else None
