@@ -15,8 +15,8 @@ eq = q.CylinderFlow(U_i0=0.6, width=1.0)
 gp = ShootProblem(eq, "kink", ctx=ctx)
 k = torch.linspace(0.01, 4.0, n, dtype=torch.float64, device="cuda")
 W = 2.7 + (torch.arange(n, dtype=torch.float64, device="cuda") + 0.5) * (4.95 - 2.7) / n
-for variant in os.environ.get("VARIANTS", "0,1,2").split(","):
-    os.environ["ES_GRID_VARIANT"] = variant
+for variant in os.environ.get("SHAPES", "4,3;2,3;1,4").split(";"):      # ES_GRID_SHAPE = points per lane, waves per SIMD
+    os.environ["ES_GRID_SHAPE"] = variant
     D, st = gp.eval_grid(k, W)
     torch.cuda.synchronize()
     ts = []
@@ -26,8 +26,8 @@ for variant in os.environ.get("VARIANTS", "0,1,2").split(","):
         torch.cuda.synchronize()
         ts.append(time.time() - t)
     t = min(ts)
-    print(f"variant {variant}: {n}x{n} grid eval {t*1e3:.1f} ms  -> {n*n/t/1e6:.1f} M det-evals/s", flush=True)
-del os.environ["ES_GRID_VARIANT"]
+    print(f"shape {variant}: {n}x{n} grid eval {t*1e3:.1f} ms  -> {n*n/t/1e6:.1f} M det-evals/s", flush=True)
+del os.environ["ES_GRID_SHAPE"]
 D, st = gp.eval_grid(k, W)
 torch.cuda.synchronize()
 t = time.time()
@@ -77,11 +77,11 @@ n2 = 2048
 rot = ShootProblem(q.CylinderRotation(v_twist=0.1, power=1.0), "kink", ctx=ctx)
 k2 = torch.linspace(0.25, 4.0, n2, dtype=torch.float64, device="cuda")
 W2 = 0.7 + (torch.arange(n2, dtype=torch.float64, device="cuda") + 0.5) * (1.45 - 0.7) / n2
-for variant in ("0", "1", "2"):
-    os.environ["ES_GRID_VARIANT"] = variant
+for variant in ("4,2", "2,2", "1,3"):
+    os.environ["ES_GRID_SHAPE"] = variant
     t = timeit(lambda: rot.eval_grid(k2, W2), reps=3)
-    print(f"K3 rotational (FAM_CYLT, {n2}x{n2}, N=2000) variant {variant}: {t*1e3:.1f} ms -> {n2*n2/t/1e6:.1f} M det-evals/s")
-del os.environ["ES_GRID_VARIANT"]
+    print(f"K3 rotational (FAM_CYLT, {n2}x{n2}, N=2000) shape {variant}: {t*1e3:.1f} ms -> {n2*n2/t/1e6:.1f} M det-evals/s")
+del os.environ["ES_GRID_SHAPE"]
 
 # K6 complex-frequency flow slab: 256 k x (64 x 64) (Re, Im) grid, N = 500, + root search
 from eigensolver_amd import SlabComplexFlow  # noqa: E402
