@@ -107,3 +107,45 @@ def test_port_unnormalised_march_compensates_axis_target():
     scale = np.abs(Dp[ok]) * 100.0 / relp[ok]
     assert np.max(np.abs(Dp[ok] - Dn[ok]) / scale) < 1e-10
     assert np.max(np.abs(Dp[ok] - base[0][ok]) / scale) > 1e-3          # the target does enter D
+
+
+@pytest.mark.parametrize("which", ["config3", "config1", "config2", "config4"])
+def test_port_vs_truth_on_the_config_grids(which):
+    """The same independent leg tests/test_full_size_parity_gpu.py runs for the HIP kernels, for the port on the CPU: 192
+    random points of the (k, omega) grid of each GPU configuration of BASELINE.json against the adaptive DOP853 oracle (no
+    RK4 grid, no code shared with kernel or port), within the discretisation bound at every point that is not within 8
+    grid columns of a flagged point (band edges: a coefficient nearly vanishes at a node), 1e-3 there."""
+    import bench
+    from tests import truth_pool
+    if which == "config3":
+        eq, mode, m = bench.workload_equilibrium(), "kink", 1
+        k, W = bench.workload_grid()
+        kind, kw = "CylinderFlow", dict(U_i0=0.7, width=0.9)
+    else:
+        _, units = bench.workload_units(which)
+        _, _, eq, mode, m, k, W = units[min(3, len(units) - 1)]
+        kind, kw = {"config1": ("SlabFlow", dict(U_i0=0.35, width=1.5)), "config2": ("CylinderDensity", dict(width=0.95)),
+                    "config4": ("CylinderRotation", dict(v_twist=0.1, power=1.0, r_axis=0.001))}[which]
+    port = cases.port_problem(eq, mode, m)
+    rng = np.random.default_rng(99)
+    n = 192
+    ii, jj = rng.integers(0, len(k), n), rng.integers(0, len(W), n)
+    kk, ww = k[ii], k[ii] * W[jj]
+    D, rel, st = port.eval_points(kk, ww, nthreads=4)
+    # statuses of the neighbouring grid columns of every sampled point (8 to either side)
+    near = np.zeros(n, dtype=bool)
+    for t in range(n):
+        cols = np.arange(max(0, jj[t] - 8), min(len(W), jj[t] + 9))
+        _, _, stn = port.eval_points(np.full(len(cols), k[ii[t]]), k[ii[t]] * W[cols], nthreads=1)
+        near[t] = (stn != 0).any()
+    tr = truth_pool.evaluate(kind, kw, mode, m, kk, ww, 4)
+    d, a, b, s = tr[:, 0], tr[:, 1], tr[:, 2], tr[:, 3].astype(int)
+    both = (s == 0) & (st == 0)
+    differ = s != st
+    assert np.all((s[differ] == 3) | (st[differ] == 3))
+    assert both.sum() > 0.5 * n
+    tol = 3e-8 * max(1.0, (1000.0 / eq.n_nodes) ** 4)
+    err = np.abs(D - d) / np.maximum(np.abs(a), np.abs(b))
+    far, edge = both & ~near, both & near
+    assert err[far].max() <= tol, (which, err[far].max())
+    assert not edge.any() or err[edge].max() <= 1e-3
