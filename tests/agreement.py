@@ -23,7 +23,12 @@ the same frequency there) and the call is put into exactly one of
   "interior_noise"  with the reference's exterior the acceptance measure is within 100 * eps_int of the tolerance
                     (acceptance flip) or the mismatch within eps_int * scale of zero (sign flip), eps_int =
                     max(3e-4, 40 * 1.5e-8 / A) being LSODA's interior error for a solution of amplitude A
-                    (the bound tests/test_oracle_golden.py holds the DOP853 oracle to on every trace);
+                    (the bound tests/test_oracle_golden.py holds the DOP853 oracle to on every trace); in the converged
+                    fixture set also the measured noise of the reference's own objective at that evaluation (`unc`);
+  "objective_noise" (converged fixture set only) the reference's re-solved slope is converged only to within the noise of
+                    its own objective (measured by the harness at that evaluation: the scatter of the objective at three
+                    abscissae 1e-6 apart, conv code 4) and the discrepancy of the mismatches is within the relative slope
+                    accuracy `unc` that noise leaves;
   "unexplained"     anything else -- the tests fail on it.
 """
 import math
@@ -77,11 +82,12 @@ class RefReplay:
         rec = q.pop(0) if len(q) > 1 else q[0]
         where, _, d, ev, es, ier = rec[:6]
         code = rec[6] if len(rec) > 6 else None
+        unc = rec[7] if len(rec) > 7 else 0.0
         A = abs(ev)
         stx, d_mix, rel_mix, outer_mix, inner_mix = self.port.eval_one(k, w, w_cst, ext=(ev, es))
         outer = outer_mix                      # cst * slope / A with the reference's slope
         dn = d / A
-        self.used.append({"w": w, "ier": ier, "conv": code, "A": A, "d_mix": d_mix, "rel_mix": rel_mix, "outer_mix": outer_mix,
+        self.used.append({"w": w, "ier": ier, "conv": code, "unc": max(0.0, unc or 0.0), "A": A, "d_mix": d_mix, "rel_mix": rel_mix, "outer_mix": outer_mix,
                           "inner_mix": inner_mix, "st_mix": stx})
         return OW.ST_OK, dn, outer, outer - dn
 
@@ -134,6 +140,15 @@ def classify_call(solver, key, call, port=None):
     pi = a["prev_idx"]
     sign_matters = (a["accepted"] == b["accepted"])          # the difference is in `refined`: a sign-product flip
     up = replay.used[pi] if pi is not None else None
+    bp = ours.log[pi] if pi is not None else None
+    flagged = b["st"] in (OW.ST_NONFINITE, OW.ST_CONTINUUM) or (sign_matters and bp is not None and
+                                                                bp["st"] in (OW.ST_NONFINITE, OW.ST_CONTINUUM))
+    # converged-fixture set: a point our evaluation flags (a coefficient of the ODE changes sign inside the domain) is the
+    # REASON the reference's solver cannot converge there -- its objective, mathematically affine, is integrator noise
+    # through the pole -- so it is looked at first; in the first fixture set the reference's own flag comes first
+    if u.get("conv") is not None and flagged:
+        out["category"] = "singular"
+        return out
     # 1. non-converged fsolve in the reference
     if u["ier"] != 1 or (sign_matters and up is not None and up["ier"] != 1):
         out["category"] = "fsolve"
@@ -147,9 +162,7 @@ def classify_call(solver, key, call, port=None):
         out["fsolve_pole"] = bool(abs(bad["outer_mix"]) <= max(NOISE_FLOOR, 40 * ATOL / bad["A"]) * abs(bad["inner_mix"])) if sc > 0 else None
         return out
     # 2. singular point (ours flags it)
-    bp = ours.log[pi] if pi is not None else None
-    if b["st"] in (OW.ST_NONFINITE, OW.ST_CONTINUUM) or (sign_matters and bp is not None and
-                                                         bp["st"] in (OW.ST_NONFINITE, OW.ST_CONTINUUM)):
+    if flagged:
         out["category"] = "singular"
         return out
     # 3. the reference's exterior error: our interior behind ITS exterior end state
@@ -196,6 +209,18 @@ def classify_call(solver, key, call, port=None):
         flip_prev = up is not None and (ref.log[pi]["d"] * up["d_mix"] < 0)
         if (flip_here and ok_here) or (flip_prev and ok_prev):
             out["category"] = "interior_noise"
+            return out
+    # 5. (converged fixture set) the noise of the reference's OWN objective, measured by the harness at this evaluation (or at
+    #    the one that supplied the previous mismatch): its re-solve converged only to within that noise (conv code 4) and the
+    #    noise leaves the slope -- in which the inner term of the mismatch is linear -- defined to `unc` relative; the
+    #    discrepancy between its mismatch and ours behind the same exterior must be within that
+    cand = [(u, disc)]
+    if up is not None and "discrepancy_prev" in out:
+        cand.append((up, out["discrepancy_prev"]))
+    for used, dsc in cand:
+        if used.get("conv") == 4 and used.get("unc", 0.0) > 0.0 and dsc <= max(used["unc"], eps):
+            out["category"] = "objective_noise"
+            out["objective_unc"] = used["unc"]
             return out
     out["category"] = "unexplained"
     return out

@@ -76,7 +76,7 @@ def load_calls(kind, name, conv=False):
                 ext = e["ext_end"]
                 if len(ext) == 4:
                     ext = [ext[0], ext[2]]
-                evs.append((e["where"], e["omega"], e["d"], ext[0], ext[1], eff(e["ier"], e.get("conv")), e.get("conv")))
+                evs.append((e["where"], e["omega"], e["d"], ext[0], ext[1], eff(e["ier"], e.get("conv")), e.get("conv"), e.get("unc") or 0.0))
             out.append({"fn": c["fn"], "k": c["k"], "freq": np.array(c["freq"]), "roots_w": c["roots_w"],
                         "n_fsolve_fail": sum(1 for e in c["evals"] if eff(e["ier"], e.get("conv")) != 1), "evals": evs})
         return out
@@ -98,7 +98,8 @@ def load_calls(kind, name, conv=False):
                 evs.append(("loop" if cols["where"][i] == 1 else "main", float(cols["omega"][i]), float(cols["d"][i]),
                             float(cols["ext_value"][i]), float(cols["ext_slope"][i]),
                             eff(int(cols["ier"][i]), int(cols["conv"][i]) if "conv" in cols else None),
-                            int(cols["conv"][i]) if "conv" in cols else None))
+                            int(cols["conv"][i]) if "conv" in cols else None,
+                            float(cols["unc"][i]) if "unc" in cols else 0.0))
         out.append({"fn": c["fn"], "k": c["k"], "freq": call_freq(c), "roots_w": c["roots_w"],
                     "n_fsolve_fail": c.get("n_unconverged", c["n_fsolve_fail"]) if conv else c["n_fsolve_fail"], "evals": evs})
     return out

@@ -141,13 +141,14 @@ def gen_case(name):
                "linspace3": [[e[1], e[2]] for e in tr if e[0] == "linspace3"],
                "evals": [{"omega": e["omega"], "d": e["d"], "ext_end": e["ext_end"], "ier": e["ier"],
                           "where": e["where"], "int_y0": e.get("int_y0"), "int_end": e.get("int_end"),
-                          "slope": e.get("slope"), **({"conv": e.get("conv")} if SUFFIX else {})} for e in evs]}
+                          "slope": e.get("slope"), **({"conv": e.get("conv"), "unc": e.get("unc")} if SUFFIX else {})} for e in evs]}
         out["calls"].append(rec)
     out["seconds"] = round(time.time() - t0, 1)
     if SUFFIX:
         out["converged_mode"] = ("fsolve calls with ier != 1 re-solved to convergence on the reference's own objective "
-                                 "(tools/ref_harness.py CONVERGE); `ier` is the flag fsolve returned, `conv` = 1 if the slope "
-                                 "the worker continued with is converged")
+                                 "(tools/ref_harness.py CONVERGE); `ier` is the flag fsolve returned, `conv` the outcome of the re-solve "
+                                 "(1 converged, 4 converged to the noise of the objective, 0 / 2 / 3 not), `unc` the relative accuracy "
+                                 "to which the objective's own noise defines the slope")
     with open(os.path.join(GOLD, f"trace_{name}{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=0)
     return f"trace_{name}{SUFFIX}.json ({out['seconds']} s, {sum(len(c['evals']) for c in out['calls'])} evals)"
@@ -271,7 +272,7 @@ def gen_rootset(name):
     ns = H.load_worker_module(key, repl)
     init = H.snapshot_initial(ns)
     out = {"case": name, "file": H.FILES[key], "replacements": repl, "calls": []}
-    cols = {c: [] for c in ("call", "omega", "d", "ext_value", "ext_slope", "ier", "where", "conv")}
+    cols = {c: [] for c in ("call", "omega", "d", "ext_value", "ext_slope", "ier", "where", "conv", "unc")}
     for k in ks:
         for b in bands:
             freq = rootset_freq(ns, b, float(k), n)
@@ -301,6 +302,7 @@ def gen_rootset(name):
                     cols["ext_slope"].append(ext[1])
                     cols["ier"].append(-1 if e["ier"] is None else e["ier"])
                     cols["conv"].append(-1 if e.get("conv") is None else e["conv"])
+                    cols["unc"].append(0.0 if e.get("unc") is None else e["unc"])
                     cols["where"].append(1 if e["where"] == "loop" else (0 if e["where"] == "main" else -1))
                 out["calls"].append(rec)
     out["seconds"] = round(time.time() - t0, 1)
@@ -309,7 +311,7 @@ def gen_rootset(name):
             out[k_] = float(ns[k_])
     with open(os.path.join(GOLD, f"roots_{name}{SUFFIX}.json"), "w") as f:
         json.dump(out, f, indent=0)
-    np.savez_compressed(os.path.join(GOLD, f"roots_{name}{SUFFIX}_evals.npz"), conv=np.array(cols["conv"], dtype=np.int8),
+    np.savez_compressed(os.path.join(GOLD, f"roots_{name}{SUFFIX}_evals.npz"), conv=np.array(cols["conv"], dtype=np.int8), unc=np.array(cols["unc"], dtype=np.float32),
                         call=np.array(cols["call"], dtype=np.int32), omega=np.array(cols["omega"]),
                         d=np.array(cols["d"]), ext_value=np.array(cols["ext_value"]),
                         ext_slope=np.array(cols["ext_slope"]), ier=np.array(cols["ier"], dtype=np.int8),

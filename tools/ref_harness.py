@@ -93,64 +93,75 @@ LSODA_ATOL = 1.5e-8          # scipy.integrate.odeint default (the scripts pass 
 
 
 def _resolve_affine(func, x_fail, x0, args):
-    """Root of the reference's objective `func`, which is affine in the slope up to the noise of its LSODA solves.
-    The derivative is taken ONCE from two abscissae far enough apart that the difference of the objective stands 1000 x above
-    LSODA's absolute tolerance (the objective of the slab scripts is ~1e-8 in size near its root: two nearby points would
-    divide noise by noise); then Newton steps with that fixed derivative.  Returns (slope, objective calls, code): 1 the step
-    fell below 1e-5 relative; 4 below 4 atol / |f'|, the accuracy to which LSODA's absolute tolerance defines the root at all;
-    0 neither after five steps; 2 the objective does not depend on the slope; 3 non-finite objective."""
+    """Root of the reference's objective `func` -- mathematically affine in the slope (a linear ODE), numerically affine plus
+    the noise of its LSODA solves.  The derivative d is taken ONCE from two abscissae far enough apart that the difference
+    of the objective stands clear of that noise; then Newton steps with the fixed d.  At every estimate s the objective is
+    also evaluated at s (1 +- 1e-6): the scatter sigma of the three values IS the noise of the reference's own objective
+    there (the affine part changes by 1e-6 |d s|), so the slope is defined to unc = max(|f(s)|, sigma) / |d s| and no better.
+    Returns (slope, objective calls, code, unc):
+      1  unc <= 1e-5: converged;
+      4  residual within three sigma of the objective's own noise: as converged as the reference's integrator allows, unc says
+         how well that is (percent-level where LSODA marches a solution that grows by many decades);
+      0  neither after four steps;  2  the objective does not depend on the slope;  3  non-finite objective."""
     def f(s):
         return float(np.real(np.ravel(func(np.array([s], dtype=float), *args))[0]))
     sa = float(np.ravel(x0)[0])
     fa = f(sa)
     n = 1
     if not np.isfinite(fa):
-        return sa, n, 3
+        return sa, n, 3, float("inf")
     step = max(abs(sa), abs(float(x_fail)) if np.isfinite(x_fail) else 0.0, 1e-6)
     d = None
-    for _ in range(8):
+    for _ in range(10):
         sb = sa + step
         fb = f(sb)
         n += 1
         if not np.isfinite(fb):
-            return sa, n, 3
-        if abs(fb - fa) > 1e3 * LSODA_ATOL:
+            return sa, n, 3, float("inf")
+        # the difference must stand clear of the noise of the objective, which is absolute (LSODA's atol) near its root and
+        # relative away from it
+        if abs(fb - fa) > 1e3 * LSODA_ATOL + 1e-3 * max(abs(fa), abs(fb)):
             d = (fb - fa) / (sb - sa)
             break
         step *= 100.0
     if d is None:
-        return sa, n, 2
+        return sa, n, 2, float("inf")
     s1 = sa - fa / d
-    for _ in range(5):
-        f1 = f(s1)
-        n += 1
-        if not np.isfinite(f1):
-            return s1, n, 3
-        sn = s1 - f1 / d
-        if abs(sn - s1) <= 1e-5 * max(abs(sn), 1e-300):
-            return sn, n, 1
-        if abs(sn - s1) <= 4.0 * LSODA_ATOL / abs(d):
-            return sn, n, 4
-        s1 = sn
-    return s1, n, 0
+    unc = float("inf")
+    for _ in range(4):
+        h = 1e-6 * abs(s1) if s1 != 0.0 else 1e-12
+        v = [f(s1), f(s1 + h), f(s1 - h)]
+        n += 3
+        if not all(np.isfinite(x) for x in v):
+            return s1, n, 3, float("inf")
+        mean = sum(v) / 3.0
+        sigma = max(abs(x - mean) for x in v)
+        unc = max(abs(v[0]), sigma) / max(abs(d * s1), 1e-300)
+        if unc <= 1e-5:
+            return s1 - v[0] / d, n, 1, unc
+        if abs(v[0]) <= 3.0 * sigma:
+            return s1, n, 4, unc
+        s1 = s1 - v[0] / d
+    return s1, n, 0, unc
 
 
 def _fsolve(func, x0, *a, **kw):
     x, info, ier, msg = scipy.optimize.fsolve(func, x0, *a, full_output=True, **kw)
     if CONVERGE and ier != 1 and np.size(x) == 1:
         try:
-            xs, n_extra, code = _resolve_affine(func, x[0], x0, kw.get("args", ()))
+            xs, n_extra, code, unc = _resolve_affine(func, x[0], x0, kw.get("args", ()))
         except Exception:
-            xs, n_extra, code = float(x[0]), 0, 3
+            xs, n_extra, code, unc = float(x[0]), 0, 3, float("inf")
         ok = code in (1, 4)
-        # conv: 1 converged to 1e-5 relative; 4 converged to the noise floor of the objective (LSODA's absolute tolerance);
-        # 0 still moving after the iterations; 2 the objective does not depend on the slope at all (the reference's
-        # interior solve fails at once); 3 non-finite objective
-        TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(xs if ok else x[0]), int(ier), int(code), int(n_extra)))
+        # conv: 1 converged to 1e-5 relative; 4 converged to the noise of the reference's own objective (unc = the relative
+        # accuracy to which that noise defines the slope); 0 neither; 2 the objective does not depend on the slope at all
+        # (the reference's interior solve fails at once); 3 non-finite objective
+        TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(xs if ok else x[0]), int(ier), int(code), int(n_extra),
+                      float(unc) if np.isfinite(unc) else -1.0))
         if ok:
             return np.array([xs], dtype=float)
         return x
-    TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(x[0]), int(ier), 1 if ier == 1 else 0, 0))
+    TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(x[0]), int(ier), 1 if ier == 1 else 0, 0, 0.0))
     return x
 
 
@@ -239,7 +250,7 @@ def evaluations(trace, n_ext=500):
     pending = None
     for ev in trace:
         if ev[0] == "odeint" and ev[3] == n_ext and abs(ev[1]) > 1.0 + 1e-12 and abs(abs(ev[2]) - 1.0) < 1e-12:
-            cur = {"ext_y0": ev[4], "ext_end": ev[5], "x_far": ev[1], "ier": None, "conv": None, "omega": pending,
+            cur = {"ext_y0": ev[4], "ext_end": ev[5], "x_far": ev[1], "ier": None, "conv": None, "unc": None, "omega": pending,
                    "d": None, "where": None, "int_end": None, "n_int": 0}
             pending = None
             evs.append(cur)
@@ -253,6 +264,7 @@ def evaluations(trace, n_ext=500):
                 cur["ier"] = ev[3]
                 cur["slope"] = ev[2]
                 cur["conv"] = ev[4] if len(ev) > 4 else (1 if ev[3] == 1 else 0)
+                cur["unc"] = ev[6] if len(ev) > 6 else 0.0
         elif ev[0] == "append":
             name = ev[1]
             if name.startswith(("all_ws", "loop_ws")):

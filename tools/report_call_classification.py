@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 from tests import agreement as A, refcases as R  # noqa: E402
 
-CATS = ["identical", "fsolve", "singular", "exterior", "interior_noise", "unexplained", "no_trace"]
+CATS = ["identical", "fsolve", "singular", "exterior", "interior_noise", "objective_noise", "unexplained", "no_trace"]
 
 
 def main():
@@ -39,12 +39,13 @@ def main():
                     if r["category"] != "identical":
                         print("   ", {k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()
                                       if k != "ours_roots"}, file=sys.stderr)
-    print("| fixture | script | calls | " + " | ".join(CATS[:5]) + " | root list identical |")
-    print("|---|---|---|" + "---|" * 6)
+    nc = 6 if conv else 5
+    print("| fixture | script | calls | " + " | ".join(CATS[:nc]) + " | root list identical |")
+    print("|---|---|---|" + "---|" * (nc + 1))
     for kind, name, key, n, sm, same in rows:
-        print(f"| {kind}:{name} | {key} | {n} | " + " | ".join(str(sm.get(c, 0)) for c in CATS[:5]) + f" | {same} |")
+        print(f"| {kind}:{name} | {key} | {n} | " + " | ".join(str(sm.get(c, 0)) for c in CATS[:nc]) + f" | {same} |")
     n_all = sum(r[3] for r in rows)
-    print(f"| **total** | | {n_all} | " + " | ".join(str(tot.get(c, 0)) for c in CATS[:5]) +
+    print(f"| **total** | | {n_all} | " + " | ".join(str(tot.get(c, 0)) for c in CATS[:nc]) +
           f" | {sum(r[5] for r in rows)} |")
     bad = tot.get("unexplained", 0) + tot.get("no_trace", 0)
     print(f"\nunexplained: {tot.get('unexplained', 0)}, without evaluation records: {tot.get('no_trace', 0)}")
