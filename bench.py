@@ -667,18 +667,33 @@ def main_units(a):
     from concurrent.futures import ThreadPoolExecutor
     dev = torch.device(f"cuda:{local_rank}")
     share = a.share_of if (world == 1 and a.share_of > 1) else 1
-    work = []
+    # lanes per unit: consecutive steps of ONE unit are pipelined over L library contexts (streams) as the steps of the
+    # headline are over --streams, so that a unit's refinement chain does not hold up its own next march; with many units
+    # the other units' marches fill that time anyway
+    n_lanes = max(1, -(-6 // len(units)))              # configs[1]: 3, configs[2]: 2, configs[4]: 1
+    if os.environ.get("ES_BENCH_UNIT_LANES"):           # A/B aids, never the judged configuration
+        n_lanes = max(1, int(os.environ["ES_BENCH_UNIT_LANES"]))
+    # ES_BENCH_GATE=1 orders the grid marches of the units one after the other by an event chain (as the steps of the
+    # headline are).  Measured on one box, ms per step without / with it: configs[1] 2.72-2.82 / 2.91-2.94, configs[2]
+    # 7.37-7.44 / 7.64-7.92, configs[4] 80.0 / 84.2 -- free-running units overlap better than ordered ones; what matters is
+    # that there is no barrier between the steps of different units (with one: 3.07, 8.03, 87.5)
+    gate = os.environ.get("ES_BENCH_GATE") == "1"
+    work, lanes = [], []
     for label, uid, eq, mode, m, k_np, W_np in units:
         rows_np = D.tile_rows(len(k_np), rank, world * share, strided=True)
-        stream = torch.cuda.Stream(device=dev)
-        cx = _lib.Context(local_rank, stream=stream)
-        cx.grid_timer(True)
-        prob = ShootProblem(eq, mode, m=m, ctx=cx)
-        work.append({"label": label, "uid": uid, "eq": eq, "prob": prob, "stream": stream, "ctx": cx,
-                     "k": torch.as_tensor(k_np[rows_np], dtype=torch.float64, device=dev),
-                     "W": torch.as_tensor(W_np, dtype=torch.float64, device=dev),
-                     "rows": torch.as_tensor(rows_np, device=dev), "nk": len(rows_np), "nw": len(W_np)})
-    pool = ThreadPoolExecutor(max_workers=len(work))
+        unit_lanes = []
+        for _ in range(n_lanes):
+            stream = torch.cuda.Stream(device=dev)
+            cx = _lib.Context(local_rank, stream=stream)
+            cx.grid_timer(True)
+            prob = ShootProblem(eq, mode, m=m, ctx=cx)
+            unit_lanes.append({"label": label, "uid": uid, "eq": eq, "prob": prob, "stream": stream, "ctx": cx,
+                               "k": torch.as_tensor(k_np[rows_np], dtype=torch.float64, device=dev),
+                               "W": torch.as_tensor(W_np, dtype=torch.float64, device=dev),
+                               "rows": torch.as_tensor(rows_np, device=dev), "nk": len(rows_np), "nw": len(W_np)})
+        lanes.append(unit_lanes)
+        work.append(unit_lanes[0])
+    pool = ThreadPoolExecutor(max_workers=len(work) * n_lanes)
     torch.cuda.synchronize()
 
     def sizing(item):
@@ -702,18 +717,46 @@ def main_units(a):
             item["cnt"] = torch.zeros(1, dtype=torch.int32, device=dev)
         item["cap"] = cap
         item["ctx"].grid_time()                       # forget the sizing launches
+    for unit_lanes in lanes:
+        for ln in unit_lanes[1:]:
+            ln["xcap"], ln["hist"], ln["cap"] = unit_lanes[0]["xcap"], unit_lanes[0]["hist"], unit_lanes[0]["cap"]
+            with torch.cuda.stream(ln["stream"]):
+                ln["table"] = ln["prob"].alloc_root_table(ln["cap"])
+                ln["cnt"] = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    import threading
+    grid_lock = threading.Lock()
+    grid_tail = [None]                             # event after the most recent grid-march launch of any unit
 
     def one_unit(item):
+        """One pass of the hot path over one unit (one lane of it) on its stream: grid march (fp64, or the fp32 screening of
+        the mixed search), bracket search, refinement, exchange buffer.  Units and lanes run free: each on its own host thread
+        and HIP stream, no barrier between them, so the latency-bound refinement chains of some overlap the throughput-bound
+        marches of others."""
         prob, stream = item["prob"], item["stream"]
         with torch.cuda.stream(stream):
+            if gate:
+                with grid_lock:
+                    if grid_tail[0] is not None:
+                        stream.wait_event(grid_tail[0])
+                    if mixed:
+                        D_, st = prob.screen_grid(item["k"], item["W"])
+                    else:
+                        D_, st = prob.eval_grid(item["k"], item["W"])
+                    tail = torch.cuda.Event()
+                    tail.record(stream)
+                    grid_tail[0] = tail
+            elif mixed:
+                D_, st = prob.screen_grid(item["k"], item["W"])
+            else:
+                D_, st = prob.eval_grid(item["k"], item["W"])
             if mixed:
-                roots, nbr, _, _, stats = prob.find_roots_mixed(item["k"], item["W"], n_bisect=N_BISECT, tol_percent=TOL_PERCENT,
-                                                                table=item["table"])
+                roots, nbr, _, _, stats = prob.find_roots_screened(item["k"], item["W"], D_, st, n_bisect=N_BISECT,
+                                                                   tol_percent=TOL_PERCENT, table=item["table"])
                 item["nre"] = stats[0] + stats[1]
                 item["count"] = count = nbr
                 full = item["table"][0]
             else:
-                D_, st = prob.eval_grid(item["k"], item["W"])
                 full = prob.find_roots_async(item["k"], item["W"], D_, st, item["table"], item["cnt"], n_bisect=N_BISECT,
                                              tol_percent=TOL_PERCENT)
                 item["nre"] = 0
@@ -723,47 +766,73 @@ def main_units(a):
             done.record(stream)
         return send, done
 
-    def step():
-        res = list(pool.map(one_unit, work))
-        if world > 1:                                  # the one exchange: ONE all-gather of all units' tables
-            cur = torch.cuda.current_stream(dev)
-            for send, done in res:
-                cur.wait_event(done)
-                send.record_stream(cur)
-            return D.gather_fixed(D.concat_fixed([r[0] for r in res]), world)
-        return None
+    import queue
+    results = queue.Queue()
 
-    for _ in range(a.warmup):
-        step()
+    def unit_loop(idx, lane, nsteps):
+        """Lane `lane` of unit `idx` runs the steps lane, lane + L, ... back to back on its own thread and stream: no barrier
+        between the steps of different units (the all-gather of step i waits for the step-i buffers of all units, the units
+        themselves go on)."""
+        for i in range(lane, nsteps, n_lanes):
+            results.put((i, idx) + one_unit(lanes[idx][lane]))
+
+    def run_steps(nsteps):
+        futs = [pool.submit(unit_loop, idx, lane, nsteps) for idx in range(len(work)) for lane in range(n_lanes)]
+        buf = None
+        if world > 1:                                  # the one exchange per step: ONE all-gather of all units' tables
+            pending = {}
+            cur = torch.cuda.current_stream(dev)
+            for i in range(nsteps):
+                while len(pending.get(i, {})) < len(work):
+                    si, idx, send, done = results.get()
+                    pending.setdefault(si, {})[idx] = (send, done)
+                sends = []
+                for idx in range(len(work)):
+                    send, done = pending[i][idx]
+                    cur.wait_event(done)
+                    send.record_stream(cur)
+                    sends.append(send)
+                del pending[i]
+                buf = D.gather_fixed(D.concat_fixed(sends), world)
+        for f in futs:
+            f.result()
+        while not results.empty():
+            results.get()
+        return buf
+
+    if a.warmup > 0:
+        run_steps(max(a.warmup, n_lanes))              # every lane at least once
         torch.cuda.synchronize()
-    for item in work:
-        item["ctx"].grid_time()
-    # the dominant kernel alone on the chip: fp64 grid launches of the middle unit back to back (first not counted)
+    for unit_lanes in lanes:
+        for ln in unit_lanes:
+            ln["ctx"].grid_time()
+    # the dominant kernel alone on the chip: grid-march launches of the middle unit back to back (first not counted)
     mid = work[len(work) // 2]
     alone = []
-    if not mixed:
-        with torch.cuda.stream(mid["stream"]):
-            for _ in range(4):
-                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                e[0].record(mid["stream"])
+    with torch.cuda.stream(mid["stream"]):
+        for _ in range(4):
+            e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e[0].record(mid["stream"])
+            if mixed:
+                mid["prob"].screen_grid(mid["k"], mid["W"])
+            else:
                 mid["prob"].eval_grid(mid["k"], mid["W"])
-                e[1].record(mid["stream"])
-                alone.append(e)
-        torch.cuda.synchronize()
-        mid["ctx"].grid_time()
+            e[1].record(mid["stream"])
+            alone.append(e)
+    torch.cuda.synchronize()
+    mid["ctx"].grid_time()
     unshared = [e0.elapsed_time(e1) for e0, e1 in alone[1:]]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        buf = step()
+    buf = run_steps(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     # per-launch duration of the grid-march kernel: HIP events inside the library, on the stream of every launch
-    gt = [item["ctx"].grid_time() for item in work]
+    gt = [ln["ctx"].grid_time() for unit_lanes in lanes for ln in unit_lanes]
     grid_ms_local = sum(t for t, _ in gt) / max(1, sum(n for _, n in gt))
     # counts of the last step, read after the timed region
     nbr = nacc = nre = 0
@@ -825,13 +894,14 @@ def main_units(a):
                "config": {"workload": desc, "precision": "mixed" if mixed else "f64", "units": len(work),
                           "grid_per_unit": [len(units[0][5]), len(units[0][6])], "k_rows_per_gpu_per_unit": mid["nk"],
                           "interior_nodes": mid["eq"].n_nodes, "n_bisect": N_BISECT, "refine_sections": 17,
-                          "refine_rounds": rounds, "refine_polish_steps": REFINE_POLISH,
+                          "refine_rounds": rounds, "refine_polish_steps": REFINE_POLISH, "pipelined_lanes_per_unit": n_lanes,
                           "grid_points_per_step": grid_points, "fp64_reevaluations_per_step": nre,
                           "brackets_per_step": nbr, "roots_per_step": nacc,
                           "grid_point_status_fractions_rank0": frac,
                           "gathered_root_records": int(merged.shape[0]) if (world > 1 and merged is not None) else 0,
                           "exchange_capacity_records_per_unit": [item["xcap"] for item in work],
-                          "parallelism": "single GPU, one HIP stream per unit" if world == 1 else
+                          "parallelism": "single GPU, one HIP stream + host thread per unit and lane, no barrier between the steps of "
+                                         "different units" if world == 1 else
                                          f"k-rows of every unit strided over {world} ranks (equal point counts), one "
                                          "RCCL all-gather of all units' root tables per step"},
                "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -841,8 +911,9 @@ def main_units(a):
                             "evals_per_launch": launch_evals, "avg_launch_ms": grid_ms, "avg_launch_ms_unshared": un,
                             "launch_note": "avg_launch_ms: HIP events around every launch of the grid-march kernel in the timed "
                                            "region, recorded by the library on the stream of the launch (es_context_grid_timer); "
-                                           "the units run on concurrent streams, so a launch shares the chip with the other "
-                                           "units' launches; avg_launch_ms_unshared: the fp64 launch of one unit alone, back to back",
+                                           "the units run free on concurrent streams, so a launch shares the chip with the marches "
+                                           "and refinements of the other units; avg_launch_ms_unshared: the same launch of one "
+                                           "unit alone, back to back",
                             "note": "fp64-VALU bound, not HBM bound (SURVEY 8d): see valu_fp64 / valu_issue"}}
         if fp64_view is not None:
             out["valu_fp64"] = fp64_view

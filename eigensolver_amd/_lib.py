@@ -173,6 +173,9 @@ def _sig(lib):
     lib.es_shoot_find_roots.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), C.POINTER(i)]
     lib.es_shoot_find_roots_mixed.argtypes = [vp, vp, vp, i, vp, i, i, i, d, vp, vp, C.POINTER(RootTable), C.POINTER(i),
                                               C.POINTER(i)]
+    lib.es_shoot_screen_grid.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp]
+    lib.es_shoot_find_roots_screened.argtypes = [vp, vp, vp, i, vp, i, i, i, d, vp, vp, C.POINTER(RootTable), C.POINTER(i),
+                                                 C.POINTER(i)]
     lib.es_shoot_find_roots_async.argtypes = [vp, vp, vp, i, vp, i, i, vp, vp, i, d, C.POINTER(RootTable), vp]
     lib.es_root_table_pack.argtypes = [vp, C.POINTER(RootTable), i, d, vp, i, vp]
     lib.es_root_table_pack_async.argtypes = [vp, C.POINTER(RootTable), vp, d, vp, i, vp]

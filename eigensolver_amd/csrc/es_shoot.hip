@@ -1529,16 +1529,54 @@ int points_into(es_context* ctx, const es_problem* prob, const double* pk, const
 }
 }  // namespace
 
+namespace {
+int check_mixed_args(es_context* ctx, const es_problem* prob, int nk, int nw, int w_mode) {
+  int rc = check_problem(ctx, prob);
+  if (rc) return rc;
+  ES_REQUIRE(ctx, nk >= 0 && nw >= 0, "negative size");
+  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  const int fam = prob->dev.family;
+  if (fam != FAM_CYL0 && fam != FAM_CYLT) {
+    ctx->last_error = "fp32 screening is implemented for the cylinder families";
+    return ES_ERR_UNSUPPORTED;
+  }
+  return ES_SUCCESS;
+}
+}  // namespace
+
+// Step 1 of the mixed search alone: the fp32 screening march, enqueued (no read-back).
+extern "C" int es_shoot_screen_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w,
+                                    int nw, int w_mode, double* d_D, uint8_t* d_status) {
+  if (!ctx) return ES_ERR_INVALID_ARG;
+  int rc = check_mixed_args(ctx, prob, nk, nw, w_mode);
+  if (rc) return rc;
+  if ((long)nk * nw == 0) return ES_SUCCESS;
+  ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
+  ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return (prob->dev.family == FAM_CYL0) ? launch_grid_f32<FAM_CYL0>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status)
+                                        : launch_grid_f32<FAM_CYLT>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+}
+
 extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
                                          const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
                                          double* d_D, uint8_t* d_status, es_root_table* table, int* h_count,
                                          int* h_stats) {
+  int rc = es_shoot_screen_grid(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+  if (rc) return rc;
+  return es_shoot_find_roots_screened(ctx, prob, d_k, nk, d_w, nw, w_mode, n_bisect, tol_percent, d_D, d_status, table,
+                                      h_count, h_stats);
+}
+
+// Steps 2 - 5 of the mixed search on a grid screened by es_shoot_screen_grid.
+extern "C" int es_shoot_find_roots_screened(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                            const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
+                                            double* d_D, uint8_t* d_status, es_root_table* table, int* h_count,
+                                            int* h_stats) {
   if (!ctx) return ES_ERR_INVALID_ARG;
-  int rc = check_problem(ctx, prob);
+  int rc = check_mixed_args(ctx, prob, nk, nw, w_mode);
   if (rc) return rc;
   ES_REQUIRE(ctx, table && h_count, "null pointer");
-  ES_REQUIRE(ctx, nk >= 0 && nw >= 0 && n_bisect >= 0 && table->capacity >= 0, "negative size");
-  ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
+  ES_REQUIRE(ctx, n_bisect >= 0 && table->capacity >= 0, "negative size");
   *h_count = 0;
   if (h_stats) h_stats[0] = h_stats[1] = h_stats[2] = 0;
   const long cells = (long)nk * nw;
@@ -1548,15 +1586,7 @@ extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob
                                            table->d_resid && table->d_row && table->d_flag),
              "null root table arrays");
   const int fam = prob->dev.family;
-  if (fam != FAM_CYL0 && fam != FAM_CYLT) {
-    ctx->last_error = "fp32 screening is implemented for the cylinder families";
-    return ES_ERR_UNSUPPORTED;
-  }
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  // 1. fp32 screening pass
-  rc = (fam == FAM_CYL0) ? launch_grid_f32<FAM_CYL0>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status)
-                         : launch_grid_f32<FAM_CYLT>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
-  if (rc) return rc;
   // 2. unsure points -> fp64
   rc = es_ensure_scan_scratch(ctx, (size_t)cells);
   if (rc) return rc;

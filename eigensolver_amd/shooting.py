@@ -189,6 +189,35 @@ class ShootProblem:
         _lib.check(self.ctx.handle, rc)
         return t
 
+    def screen_grid(self, k, w, w_mode=W_PHASE_SPEED):
+        """Step 1 of the mixed search alone (es_shoot_screen_grid): the fp32 screening march, enqueued.  Returns the
+        screened (D, status) for find_roots_screened."""
+        import torch
+        dk, dw = self._dev(k).reshape(-1), self._dev(w)
+        nk = dk.numel()
+        nw = dw.shape[-1] if w_mode == W_PER_ROW else dw.numel()
+        D = torch.empty((nk, nw), dtype=torch.float64, device=dk.device)
+        st = torch.empty((nk, nw), dtype=torch.uint8, device=dk.device)
+        rc = self.ctx.lib.es_shoot_screen_grid(self.ctx.handle, self.handle, _lib.ptr(dk), nk, _lib.ptr(dw), nw, w_mode,
+                                               _lib.ptr(D), _lib.ptr(st))
+        _lib.check(self.ctx.handle, rc)
+        return D, st
+
+    def find_roots_screened(self, k, w, D, st, w_mode=W_PHASE_SPEED, n_bisect=40, tol_percent=1e-3, table=None, capacity=None):
+        """Steps 2 - 5 of the mixed search on a grid screened by screen_grid; returns what find_roots_mixed returns."""
+        dk, dw = self._dev(k).reshape(-1), self._dev(w)
+        nk = dk.numel()
+        nw = dw.shape[-1] if w_mode == W_PER_ROW else dw.numel()
+        t, rt = table if table is not None else self.alloc_root_table(int(capacity) if capacity is not None else max(1024, 16 * nk))
+        n = C.c_int(0)
+        stats = (C.c_int * 3)()
+        rc = self.ctx.lib.es_shoot_find_roots_screened(self.ctx.handle, self.handle, _lib.ptr(dk), nk, _lib.ptr(dw), nw,
+                                                       w_mode, int(n_bisect), float(tol_percent), _lib.ptr(D), _lib.ptr(st),
+                                                       C.byref(rt), C.byref(n), stats)
+        _lib.check(self.ctx.handle, rc, allow_capacity=True)
+        m = min(n.value, rt.capacity)
+        return {key: v[:m] for key, v in t.items()}, n.value, D, st, tuple(stats)
+
     def find_roots_mixed(self, k, w, w_mode=W_PHASE_SPEED, n_bisect=40, tol_percent=1e-3, capacity=None, table=None):
         """fp32 screening of the grid + fp64 re-evaluation of every unsure point and of both ends of every bracket +
         fp64 refinement (es_shoot_find_roots_mixed).  Returns (root dict, bracket count, D, status, stats) with

@@ -241,6 +241,17 @@ int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const dou
                               const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
                               double* d_D, uint8_t* d_status, es_root_table* table, int* h_count, int* h_stats);
 
+/* The two halves of es_shoot_find_roots_mixed as separate calls (same result when called one after the other on the same
+ * arrays): es_shoot_screen_grid enqueues step 1, the fp32 screening march (nothing read back); es_shoot_find_roots_screened
+ * runs steps 2 - 5 on the screened d_D / d_status.  A caller that runs several problems on several streams can then order
+ * the throughput-bound screening launches one after the other and let the latency-bound remainder of one problem run under
+ * the screening of the next (bench.py --workload config4). */
+int es_shoot_screen_grid(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw,
+                         int w_mode, double* d_D, uint8_t* d_status);
+int es_shoot_find_roots_screened(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
+                                 const double* d_w, int nw, int w_mode, int n_bisect, double tol_percent,
+                                 double* d_D, uint8_t* d_status, es_root_table* table, int* h_count, int* h_stats);
+
 /* Send buffer of the multi-GPU exchange (one all-gather of fixed-capacity buffers per step):
  * d_out is (cap + 1) x 6 doubles, row 0 = (count, 0, ...), rows 1 .. min(count, cap) = (k, omega, m, resid, flag,
  * global row) of the first records of `table`, the rest zero.  d_rows_global[local row] maps the rows of a k-tile to
