@@ -365,6 +365,7 @@ def main():
     import threading
     grid_lock = threading.Lock()
     grid_tail = [None]                             # event after the most recent grid launch of any lane
+    no_gate = os.environ.get("ES_BENCH_NO_GATE") == "1"     # A/B aid: grid launches of the lanes not ordered
 
     def compute(j, ev=None):
         """One pass of the hot path over the rank's tile on lane j, everything enqueued and NOTHING read back: grid, bracket
@@ -375,7 +376,7 @@ def main():
             # grid launches of different lanes run one after the other (each has the whole chip, and the events below
             # time one launch); what overlaps with the NEXT step's grid is this step's bracket search and refinement
             with grid_lock:
-                if grid_tail[0] is not None:
+                if grid_tail[0] is not None and not no_gate:
                     stream.wait_event(grid_tail[0])
                 if ev is not None:
                     ev[0].record(stream)
