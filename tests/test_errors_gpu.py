@@ -103,3 +103,57 @@ def test_round2_entry_points_reject_bad_input_and_handle_edges(es_ctx):
     es_ctx.synchronize()
     assert float(out[0, 0]) == 0.0 and float(out.abs().sum()) == 0.0
     gp.close()
+
+
+def test_round3_entry_points_reject_bad_arguments(es_ctx, monkeypatch):
+    """es_shoot_find_roots_async, es_root_table_pack_async, es_shoot_grid_shape, es_shoot_screen_grid /
+    es_shoot_find_roots_screened, es_context_grid_time: null pointers, sizes, families; an unbuilt ES_GRID_SHAPE is an
+    error with a message, not a silent fall-back; empty grids are fine."""
+    import torch
+    from eigensolver_amd import _lib, ShootProblem, equilibrium as q
+    lib = es_ctx.lib
+    gp = ShootProblem(q.CylinderFlow(U_i0=0.6, width=1.0), "kink", ctx=es_ctx)
+    k = torch.linspace(0.5, 3.0, 4, dtype=torch.float64, device="cuda")
+    W = torch.linspace(2.8, 4.9, 32, dtype=torch.float64, device="cuda")
+    D, st = gp.eval_grid(k, W)
+    t, rt = gp.alloc_root_table(64)
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    args = (es_ctx.handle, gp.handle, _lib.ptr(k), 4, _lib.ptr(W), 32, 1, _lib.ptr(D), _lib.ptr(st), 16, 1e-3, C.byref(rt))
+    assert lib.es_shoot_find_roots_async(*args, None) == 1                                     # no count word
+    assert lib.es_shoot_find_roots_async(*args[:6], 9, *args[7:], _lib.ptr(cnt)) == 1          # w_mode
+    assert lib.es_shoot_find_roots_async(None, *args[1:], _lib.ptr(cnt)) == 1
+    assert lib.es_shoot_find_roots_async(*args, _lib.ptr(cnt)) == 0
+    # empty grid: count zeroed on the device, nothing launched
+    cnt.fill_(7)
+    assert lib.es_shoot_find_roots_async(es_ctx.handle, gp.handle, _lib.ptr(k), 0, _lib.ptr(W), 32, 1, _lib.ptr(D), _lib.ptr(st),
+                                         16, 1e-3, C.byref(rt), _lib.ptr(cnt)) == 0
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0
+    out = torch.empty((9, 6), dtype=torch.float64, device="cuda")
+    assert lib.es_root_table_pack_async(es_ctx.handle, C.byref(rt), None, 1.0, None, 8, _lib.ptr(out)) == 1
+    assert lib.es_root_table_pack_async(es_ctx.handle, C.byref(rt), _lib.ptr(cnt), 1.0, None, 8, _lib.ptr(out)) == 0
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert lib.es_shoot_grid_shape(es_ctx.handle, gp.handle, 0, C.byref(a), C.byref(b), C.byref(c)) == 1
+    assert lib.es_shoot_grid_shape(es_ctx.handle, gp.handle, 1024, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert a.value in (1, 2, 4) and b.value in (2, 3, 4)
+    ms, n = C.c_double(0), C.c_int(0)
+    assert lib.es_context_grid_time(es_ctx.handle, None, C.byref(n)) == 1
+    # a launch shape outside the build is refused
+    monkeypatch.setenv("ES_GRID_SHAPE", "1,2")
+    with pytest.raises(_lib.EsError, match="shape"):
+        gp.eval_grid(k, W)
+    monkeypatch.delenv("ES_GRID_SHAPE")
+    gp.eval_grid(k, W)
+    # the halves of the mixed search: slabs are unsupported, the screened half needs table and count
+    gs = ShootProblem(q.SlabFlow(U_i0=0.35, width=1.5), "kink", ctx=es_ctx)
+    with pytest.raises(_lib.EsError, match="unsupported"):
+        gs.screen_grid(k, W)
+    Ds, ss = gp.screen_grid(k, W)
+    nn = C.c_int(0)
+    assert lib.es_shoot_find_roots_screened(es_ctx.handle, gp.handle, _lib.ptr(k), 4, _lib.ptr(W), 32, 1, 16, 1e-3, _lib.ptr(Ds),
+                                            _lib.ptr(ss), None, C.byref(nn), None) == 1
+    r1 = gp.find_roots_screened(k, W, Ds, ss, n_bisect=16, table=(t, rt))
+    r2 = gp.find_roots_mixed(k, W, n_bisect=16)
+    assert r1[1] == r2[1] and torch.equal(r1[0]["w"], r2[0]["w"])
+    gs.close()
+    gp.close()
