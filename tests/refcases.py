@@ -64,7 +64,7 @@ def load_calls(kind, name, conv=False):
 
     def eff(ier, cv):
         # conv codes of tools/ref_harness.py: 1 converged, 4 converged to the noise floor of the reference's own objective
-        return 1 if (conv and cv in (1, 4)) else ier
+        return 1 if (conv and cv in (1, 4, 5)) else ier
     if kind == "trace":
         tr = json.load(open(os.path.join(G, f"trace_{name}{sfx}.json")))
         out = []

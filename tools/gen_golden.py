@@ -279,7 +279,7 @@ def gen_rootset(name):
             for fn in modes:
                 rw, rk, tr = H.run_worker(ns, init, fn, float(k), freq)
                 iers = [e[3] for e in tr if e[0] == "fsolve"]
-                unconv = [e for e in tr if e[0] == "fsolve" and (e[4] if len(e) > 4 else int(e[3] == 1)) not in (1, 4)]
+                unconv = [e for e in tr if e[0] == "fsolve" and (e[4] if len(e) > 4 else int(e[3] == 1)) not in (1, 4, 5)]
                 evs = H.evaluations(tr)
                 rec = {"fn": fn, "k": float(k), "n": len(freq), "roots_w": rw, "n_evals": len(evs),
                        "n_fsolve_fail": int(sum(1 for i in iers if i != 1))}

@@ -153,7 +153,7 @@ def _fsolve(func, x0, *a, **kw):
         except Exception:
             xs, n_extra, code, unc = float(x[0]), 0, 3, float("inf")
         ok = code in (1, 4)
-        # conv: 1 converged to 1e-5 relative; 4 converged to the noise of the reference's own objective (unc = the relative
+        # conv: 1 converged to 1e-5 relative (5: the same after fsolve had claimed convergence at a slope that is no root); 4 converged to the noise of the reference's own objective (unc = the relative
         # accuracy to which that noise defines the slope); 0 neither; 2 the objective does not depend on the slope at all
         # (the reference's interior solve fails at once); 3 non-finite objective
         TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(xs if ok else x[0]), int(ier), int(code), int(n_extra),
@@ -161,6 +161,28 @@ def _fsolve(func, x0, *a, **kw):
         if ok:
             return np.array([xs], dtype=float)
         return x
+    if CONVERGE and ier == 1 and np.size(x) == 1:
+        # fsolve's ier = 1 only says that its step fell below xtol; verify the root on the objective itself: if the Newton
+        # correction the objective asks for at the returned slope (two calls, abscissae 0.1 % apart) exceeds 1e-5 of the
+        # slope and the residual stands above LSODA's absolute tolerance, the "converged" slope is not a root (seen in SF-U's
+        # driver sweep: a mismatch of the wrong sign between two re-solved neighbours) and is re-solved like the others
+        try:
+            args = kw.get("args", ())
+            xv = float(x[0])
+            h = 1e-3 * abs(xv) if xv != 0.0 else 1e-9
+            f0 = float(np.real(np.ravel(func(np.array([xv], dtype=float), *args))[0]))
+            f1 = float(np.real(np.ravel(func(np.array([xv + h], dtype=float), *args))[0]))
+            dloc = (f1 - f0) / h
+            if np.isfinite(f0) and np.isfinite(dloc) and dloc != 0.0 and abs(f0) > 4.0 * LSODA_ATOL and \
+                    abs(f0 / dloc) > 1e-5 * max(abs(xv), 1e-300):
+                xs, n_extra, code, unc = _resolve_affine(func, xv, x0, args)
+                if code in (1, 4) and abs(xs - xv) > 1e-5 * max(abs(xs), abs(xv)):
+                    # conv 5: fsolve claimed convergence, the objective disagrees, re-solved
+                    TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(xs), int(ier), 5, int(n_extra) + 2,
+                                  float(unc) if np.isfinite(unc) else -1.0))
+                    return np.array([xs], dtype=float)
+        except Exception:
+            pass
     TRACE.append(("fsolve", float(np.ravel(x0)[0]), float(x[0]), int(ier), 1 if ier == 1 else 0, 0, 0.0))
     return x
 
