@@ -552,21 +552,76 @@ __device__ __forceinline__ v2f vrcp(v2f a) { return (v2f){__builtin_amdgcn_rcpf(
 struct CoefF { v2f a11, a12, a21, a22; };
 struct CoefPreF { v2f n11, n12, n21, n22, den; };
 
-// What the screening pass remembers per point about the watched terms of the coefficient set:
-//   band families (status known exactly from W = omega/k): the minimum over the nodes of |t1 t2| = |den| / (rho S) --
-//     how close Om^2 came to omega_A^2 or omega_c^2 (1 instruction per point and node);
-//   tracked families: running minimum and maximum of t1 and t2 and, twisted family, the sign bits of C3 D as in the
-//     fp64 kernel plus the minimum of |C3| - tau |D (rho t1 + r d/dr[..])| (how close C3 came to zero relative to its
-//     leading part).
-// With S = tau (omega^2 + omega_A^2(boundary)) a tracked term is certainly of one sign if min > S or max < -S, certainly
-// crossing zero if min < -S and max > S (=> ES_PT_CONTINUUM whatever happens next to the zero); anything else sends the
-// point to fp64.
+// What the screening pass knows about the watched terms of the coefficient set:
+//   band families (status known exactly from W = omega/k): per point the minimum over the nodes of |t1 t2| = |den| / (rho S)
+//     -- how close Om^2 came to omega_A^2 or omega_c^2 (1 instruction per point and node);
+//   tracked families: t1 = (omega - e0)^2 - omega_A^2 is negative at node j exactly for omega inside the interval
+//     (e0_j - |omega_A,j|, e0_j + |omega_A,j|), t2 likewise with omega_c: the workgroup accumulates, while it stages the
+//     node entries of its row, the extremes of the interval ends over all nodes -- min / max of the lower ends, min / max of
+//     the upper ends, max of 1 / half-width (RowBands) -- and judges every point against these ten numbers AFTER the march
+//     (round 2 kept running minima and maxima of t1 and t2 per point and node: 56 of the 560 VALU instructions of a loop
+//     iteration).  With S = tau (omega^2 + omega_A^2(boundary)) and delta = S max_j(1 / a_j): all t_j > S if omega is more
+//     than delta outside every interval, all t_j < -S if it is more than delta inside every interval; anything else -- the
+//     continuum points and a margin around the band edges -- goes to fp64, which decides with the per-node tracking of
+//     the fp64 kernels.  Twisted family in addition, per point: the sign bits of C3 D as in the fp64 kernel and the minimum of
+//     |C3| - tau |D (rho t1 + r d/dr[..])| (how close C3 came to zero relative to its leading part).
 template <bool TRACK>
 struct ScreenF {
   v2f mn = {3.0e38f, 3.0e38f};                          // !TRACK: min |t1 t2|
-  v2f lo1 = {3.0e38f, 3.0e38f}, hi1 = {-3.0e38f, -3.0e38f}, lo2 = {3.0e38f, 3.0e38f}, hi2 = {-3.0e38f, -3.0e38f};
   v2f c3m = {3.0e38f, 3.0e38f};
   int or3[2] = {0, 0}, and3[2] = {-1, -1};
+};
+
+// extremes over the nodes of a row of the intervals in which t1 (index 0) and t2 (index 1) are negative; fp32, rounded
+// OUTWARDS (a bound that is off by an ulp must err on the side of "unsure")
+struct RowBands {
+  float lo_min[2] = {3.0e38f, 3.0e38f}, lo_max[2] = {-3.0e38f, -3.0e38f};
+  float hi_min[2] = {3.0e38f, 3.0e38f}, hi_max[2] = {-3.0e38f, -3.0e38f};
+  float inv_a[2] = {0.0f, 0.0f};
+  __device__ __forceinline__ static float down(double x) { const float f = (float)x; return f - fabsf(f) * 2.4e-7f - 1e-37f; }
+  __device__ __forceinline__ static float up(double x) { const float f = (float)x; return f + fabsf(f) * 2.4e-7f + 1e-37f; }
+  __device__ __forceinline__ void add(int t, double centre, double a) {
+    const double lo = centre - a, hi = centre + a;
+    lo_min[t] = fminf(lo_min[t], down(lo)); lo_max[t] = fmaxf(lo_max[t], up(lo));
+    hi_min[t] = fminf(hi_min[t], down(hi)); hi_max[t] = fmaxf(hi_max[t], up(hi));
+    inv_a[t] = fmaxf(inv_a[t], (a > 0.0) ? up(1.0 / a) : 3.0e38f);
+  }
+  // all lanes of the workgroup end up with the extremes over the whole workgroup; `red` = 10 * (T / 64) floats of LDS
+  __device__ __forceinline__ void reduce(float* red, int T) {
+    float v[10] = {lo_min[0], lo_min[1], hi_min[0], hi_min[1], -lo_max[0], -lo_max[1], -hi_max[0], -hi_max[1], -inv_a[0], -inv_a[1]};
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v[i] = fminf(v[i], __shfl_xor(v[i], off));
+    const int wave = threadIdx.x >> 6, nwaves = T >> 6;
+    __syncthreads();                                   // the LDS table of the last chunk is no longer read
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) red[wave * 10 + i] = v[i];
+    __syncthreads();
+    for (int wv = 0; wv < nwaves; ++wv)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) v[i] = fminf(v[i], red[wv * 10 + i]);
+    lo_min[0] = v[0]; lo_min[1] = v[1]; hi_min[0] = v[2]; hi_min[1] = v[3];
+    lo_max[0] = -v[4]; lo_max[1] = -v[5]; hi_max[0] = -v[6]; hi_max[1] = -v[7]; inv_a[0] = -v[8]; inv_a[1] = -v[9];
+  }
+  // 0: every t_j of term t is certainly > S;  1: certainly < -S;  -1: cannot tell.
+  // t = (|Om| - a)(|Om| + a): outside an interval by d, t > d (d + 2 a), i.e. > S once d >= sqrt(S) or d >= S / (2 a);
+  // inside by d, -t > d a, i.e. > S once d >= S / a.
+  __device__ __forceinline__ int sign_of(int t, double w, double S) const {
+    const double d_in = S * (double)inv_a[t];
+    const double d_out = fmin(sqrt(S), 0.5 * d_in);
+    if (w < (double)lo_min[t] - d_out || w > (double)hi_max[t] + d_out) return 0;
+    if (w > (double)lo_max[t] + d_in && w < (double)hi_min[t] - d_in) return 1;
+    return -1;
+  }
+  // the same for ONE node (interval centre e0, half-width a, both fp64): +1 / -1 certain sign of t there, 0 cannot tell
+  __device__ __forceinline__ static int node_sign(double w, double S, double e0, double a) {
+    const double d = fabs(w - e0) - a;
+    if (d >= fmin(sqrt(S), a > 0.0 ? 0.5 * S / a : INFINITY) * (1.0 + 1e-6)) return 1;
+    if (a > 0.0 && -d >= (S / a) * (1.0 + 1e-6)) return -1;
+    return 0;
+  }
 };
 
 template <int FAM, bool TRACK>
@@ -576,12 +631,7 @@ __device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, v2f w
   const v2f t1 = Om2 - v2(e[1]);
   const v2f t2 = Om2 - v2(e[2]);
   const v2f t12 = t1 * t2;
-  if (TRACK) {
-    sc.lo1 = vmin(sc.lo1, t1); sc.hi1 = vmax(sc.hi1, t1);
-    sc.lo2 = vmin(sc.lo2, t2); sc.hi2 = vmax(sc.hi2, t2);
-  } else {
-    sc.mn = vmin(sc.mn, vabs(t12));
-  }
+  if (!TRACK) sc.mn = vmin(sc.mn, vabs(t12));
   if (FAM == FAM_CYL0) {
     C.n11 = v2(0.0f);
     C.n12 = v2(e[3]) * t1;
@@ -685,6 +735,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
     const bool wave_live = __any(lane_live);
     const bool wg_live = __syncthreads_or(wave_live ? 1 : 0) != 0;
     const int nchunks = wg_live ? (nsteps + CH - 1) / CH : 0;
+    RowBands bands;
     for (int c = nchunks - 1; c >= 0; --c) {
       const int c0 = c * CH;
       const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
@@ -695,6 +746,10 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
         make_entry<FAM>(b, s, e);                      // fp64, rounded to fp32 once
 #pragma unroll
         for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = (float)e[f];
+        if (TRACK) {                                   // where t1 / t2 are negative at this node: omega within a of e0
+          bands.add(0, e[0], sqrt(e[1]));
+          bands.add(1, e[0], sqrt(e[2]));
+        }
       }
       __syncthreads();
       if (!wave_live) continue;
@@ -759,9 +814,21 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       }
 #undef ES_F32_STEP
     }
+    if (TRACK && wg_live) bands.reduce(lds, T);        // workgroup-uniform condition (the reduction has barriers)
     double bf[FamTraits<FAM>::NB], ef[NE];
     load_base<FAM>(P, 0, bf);
     make_entry<FAM>(bf, s, ef);
+    double emid[3] = {0.0, 0.0, 0.0}, elast[3] = {0.0, 0.0, 0.0};     // e0, omega_A^2, omega_c^2 of two more sampled nodes
+    if (TRACK) {
+      double et[NE];
+      load_base<FAM>(P, P.npts / 2, bf);
+      make_entry<FAM>(bf, s, et);
+      emid[0] = et[0]; emid[1] = et[1]; emid[2] = et[2];
+      load_base<FAM>(P, P.npts - 1, bf);
+      make_entry<FAM>(bf, s, et);
+      elast[0] = et[0]; elast[1] = et[1]; elast[2] = et[2];
+      load_base<FAM>(P, 0, bf);
+    }
 #pragma unroll
     for (int p = 0; p < PTS; ++p) {
       const int iw = w0 + p * T + (int)threadIdx.x;
@@ -788,12 +855,23 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
         const float sz = (float)(w * w + ef[1]);
         node_unsure = !crossed && !(mnp > F32_TAU_NODE * sz * sz);
       } else {
-        const float lo1 = hi_half ? sc.lo1.y : sc.lo1.x, hi1 = hi_half ? sc.hi1.y : sc.hi1.x;
-        const float lo2 = hi_half ? sc.lo2.y : sc.lo2.x, hi2 = hi_half ? sc.hi2.y : sc.hi2.x;
         const float c3m = hi_half ? sc.c3m.y : sc.c3m.x;
         const int or3 = sc.or3[p & 1], and3 = sc.and3[p & 1];
-        const bool cross12 = (lo1 < -S && hi1 > S) || (lo2 < -S && hi2 > S);
-        const bool sure12 = (lo1 > S || hi1 < -S) && (lo2 > S || hi2 < -S);
+        // t1, t2: certainly of one sign at every node (judged from the row's interval extremes); or certainly of BOTH signs
+        // inside the domain, seen at three sampled nodes (boundary, middle, far end: one of them certainly negative, another
+        // certainly positive => ES_PT_CONTINUUM whatever happens in between -- most of a continuum band of a monotone
+        // profile); anything else is the margin fp64 decides
+        const bool sure12 = bands.sign_of(0, w, (double)S) >= 0 && bands.sign_of(1, w, (double)S) >= 0;
+        bool cross12 = false;
+        if (!sure12) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int s0 = RowBands::node_sign(w, (double)S, ef[0], sqrt(ef[1 + t]));
+            const int s1 = RowBands::node_sign(w, (double)S, emid[0], sqrt(emid[1 + t]));
+            const int s2 = RowBands::node_sign(w, (double)S, elast[0], sqrt(elast[1 + t]));
+            cross12 = cross12 || ((s0 < 0 || s1 < 0 || s2 < 0) && (s0 > 0 || s1 > 0 || s2 > 0));
+          }
+        }
         if (cross12) {
           crossed = true; node_unsure = false;
         } else if (sure12 && (FAM != FAM_CYLT || c3m >= 0.0f)) {
