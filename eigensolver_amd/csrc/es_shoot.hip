@@ -406,7 +406,9 @@ constexpr int REFINE_WAVES = 4;
 // SIMD's 512 registers) except for the twisted family, which needs 234 and would spill (WPE = 2).
 // CHR > 0: the node entries of a bracket are formed once per chunk of CHR steps by the wave into its own LDS table and
 // shared by the LANES lanes of the bracket (shoot_point_wavegroup); CHR = 0: every lane forms its own (shoot_point).
-template <int FAM, int LANES, int CHR = 0, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+// SECTIONS_ONLY (n_polish < 0, what launch_refine uses whenever there is a section round): no status is needed from the
+// evaluations (shoot_point<FAM, false>).
+template <int FAM, int LANES, int CHR = 0, bool SECTIONS_ONLY = false, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n, int n_max,
                    int n_rounds, int n_polish, double tol_percent) {                      // d_lo / d_hi alias table columns
@@ -449,6 +451,7 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, co
       x = lo + (hi - lo) * 0.5;                        // n_polish = 0: report the bracket mid-point
     }
     if (CHR > 0) shoot_point_wavegroup<FAM, (CHR > 0 ? CHR : 1), GROUPS>(P, k, x, D, rel, st, es_point_lds + ((int)threadIdx.x >> 6) * WTBL);
+    else if (SECTIONS_ONLY) shoot_point<FAM, false>(P, k, x, x, D, rel, st, es_point_lds);
     else shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
     if (section) {
       const bool diff = (D * flo < 0.0);               // NaN products compare false, as in the reference
@@ -1153,18 +1156,20 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   if (const char* ev = getenv("ES_REFINE_SHARED_MIN")) shared_min = atoi(ev);
   const bool shared_entries = CHR > 0 && np < 0 && n_hint >= shared_min && !getenv("ES_REFINE_PRIVATE_ENTRIES");
   auto blocks = [&](int per_wg) { return dim3((n_max + per_wg - 1) / per_wg); };
-  if (sections == 17 && shared_entries)
-    hipLaunchKernelGGL((refine_kernel<FAM, 16, CHR>), blocks(4 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
-                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
-  else if (sections == 17)
-    hipLaunchKernelGGL((refine_kernel<FAM, 16>), blocks(4 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
-                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
-  else if (sections == 9)
-    hipLaunchKernelGGL((refine_kernel<FAM, 8>), blocks(8 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
-                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
-  else
-    hipLaunchKernelGGL((refine_kernel<FAM, 4>), blocks(16 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
-                       prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol);
+#define ES_REFINE(LANES_, CHR_, SO_, PER_WG_)                                                                           \
+  hipLaunchKernelGGL((refine_kernel<FAM, LANES_, CHR_, SO_>), blocks(PER_WG_), dim3(64 * REFINE_WAVES), 0, ctx->stream, \
+                     prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol)
+  if (sections == 17 && shared_entries) ES_REFINE(16, CHR, true, 4 * REFINE_WAVES);       // shared entries imply np < 0
+  else if (np < 0) {
+    if (sections == 17) ES_REFINE(16, 0, true, 4 * REFINE_WAVES);
+    else if (sections == 9) ES_REFINE(8, 0, true, 8 * REFINE_WAVES);
+    else ES_REFINE(4, 0, true, 16 * REFINE_WAVES);
+  } else {
+    if (sections == 17) ES_REFINE(16, 0, false, 4 * REFINE_WAVES);
+    else if (sections == 9) ES_REFINE(8, 0, false, 8 * REFINE_WAVES);
+    else ES_REFINE(4, 0, false, 16 * REFINE_WAVES);
+  }
+#undef ES_REFINE
   ES_HIP_CHECK(ctx, hipGetLastError());
   if (np < 0) {
     hipLaunchKernelGGL((refine_polish_kernel<FAM>), blocks(64 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,

@@ -62,7 +62,7 @@ __device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& 
 // LDS address per node (broadcast) and forms its own node entries.  Same arithmetic, in the same order, as the grid
 // kernel.  (Reading the table with wave-uniform scalar loads instead left these latency-bound kernels -- one wave
 // per SIMD or fewer -- waiting ~400 ns per RK4 step.)
-template <int FAM, bool TRACK>
+template <int FAM, bool TRACK, bool BANDS = !TRACK>
 __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, double w, double w_cst, double& D,
                                                  double& rel, uint8_t& st, double* __restrict__ sb) {
   constexpr int NE = FamTraits<FAM>::NE;
@@ -107,7 +107,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
     adjoint_rescale<FAM>(zp, zq, nsteps - c0 - nst, nsteps - c0);   // steps marched before / after this chunk
   }
   const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
-  finish_point(P, M, X, TRACK ? trk.crossed() : band_crossed(P, k, w), D, rel, st);
+  finish_point(P, M, X, TRACK ? trk.crossed() : (BANDS ? band_crossed(P, k, w) : false), D, rel, st);
 }
 
 // The 64 lanes of a WAVE fall into NG groups of 64 / NG lanes with the SAME k each (the section points of one bracket):
@@ -185,10 +185,16 @@ __device__ __forceinline__ void shoot_point_wavegroup(const ShootDev& P, double 
   else shoot_point_wavegroup_impl<FAM, true, CHR, NG>(P, k, w, D, rel, st, tbl);
 }
 
-template <int FAM>
+// STATUS = false: the caller only uses D (section rounds of the refinement: the sign of D steers them, the status of a
+// section point is never looked at -- the classification comes from the last polish evaluation): no per-node sign
+// tracking (12 integer instructions per point-step for the twisted family), ES_PT_CONTINUUM is then never reported;
+// D, rel and the other statuses are the same bits.
+template <int FAM, bool STATUS = true>
 __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
                                             double& rel, uint8_t& st, double* __restrict__ sb) {
-  if (fam_has_bands<FAM>() && P.use_bands) shoot_point_impl<FAM, !fam_has_bands<FAM>()>(P, k, w, w_cst, D, rel, st, sb);   // uniform branch
+  if (!STATUS) {
+    shoot_point_impl<FAM, false, false>(P, k, w, w_cst, D, rel, st, sb);
+  } else if (fam_has_bands<FAM>() && P.use_bands) shoot_point_impl<FAM, !fam_has_bands<FAM>()>(P, k, w, w_cst, D, rel, st, sb);   // uniform branch
   else shoot_point_impl<FAM, true>(P, k, w, w_cst, D, rel, st, sb);
 }
 
