@@ -80,3 +80,17 @@ def test_grid_path_fuzz_all_families(es_ctx):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(80, seed=3) == 0
+
+
+def test_fuzz_grid_with_independent_dop853_leg():
+    """tools/fuzz_grid.py in small: 80 random problems of all families -- GPU grid path against the port (statuses, D to 1e-12
+    of the scale, skip-continuum mode, bracket tables, roots) AND two evaluated points of every problem against the adaptive
+    DOP853 oracle, which shares neither the RK4 grid nor code with kernel or port (300 problems / 532 points run the same way
+    on the GPU box: 0 above the bound, worst 0.14 of it)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_grid.py")
+    spec = importlib.util.spec_from_file_location("fuzz_grid", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(80, seed=23, n_truth=80) == 0

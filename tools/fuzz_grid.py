@@ -1,7 +1,10 @@
 """GPU fuzz of the fp64 grid path against the CPU port (oracle/c/shoot_port.c) over random problems of all four
 families: statuses identical, |dD| <= 1e-12 of the scale at every ES_PT_OK point, ES_EVAL_SKIP_CONTINUUM identical
 outside the continuum, grid search identical to the port's (bracket rows, flags, roots to 1e-10).
-    python tools/fuzz_grid.py [n_cases [seed]]"""
+    python tools/fuzz_grid.py [n_cases [seed [n_truth]]]
+n_truth > 0: an INDEPENDENT leg for the first n_truth cases -- two evaluated points of each (at least 8 columns away from any
+flagged point of their row) against the adaptive DOP853 oracle (oracle/cylinder.py, oracle/slab.py: no RK4 grid, no code
+shared with kernel or port), within the discretisation bound 3e-8 (1000 / N)^4 of the scale."""
 import os
 import sys
 
@@ -34,11 +37,12 @@ def random_problem(rng):
     return q.SlabFlow(U_i0=float(rng.uniform(0.0, 0.5)), width=float(rng.choice([0.9, 1.5, 1e5]))), mode, None, (-2.45, 2.45)
 
 
-def main(n_cases, seed=5):
+def main(n_cases, seed=5, n_truth=0):
     import torch
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
     worst, bad = 0.0, 0
+    truth_worst, truth_n, truth_bad = 0.0, 0, 0
     for c in range(n_cases):
         eq, mode, m, (lo, hi) = random_problem(rng)
         nk, nw = int(rng.integers(2, 9)), int(rng.integers(40, 400))
@@ -78,13 +82,34 @@ def main(n_cases, seed=5):
                 msg.append(f"roots differ by more than 1e-10: d={dw[i]:.2e} at k={rp['k'][i]:.4f} w={rp['w'][i]:.6f} "
                            f"[{rp['w_lo'][i]:.6f}, {rp['w_hi'][i]:.6f}] resid gpu {float(r['resid'][i]):.3e} port {rp['resid'][i]:.3e} "
                            f"bracket width gpu {float(r['w_hi'][i] - r['w_lo'][i]):.2e} port {rp['w_hi'][i] - rp['w_lo'][i]:.2e}")
+        if c < n_truth and ok.any():
+            flagged = st != 0
+            cand = [(i, j) for i in range(len(k)) for j in range(8, len(W) - 8)
+                    if ok[i, j] and not flagged[i, j - 8:j + 9].any()]
+            if cand:
+                truth = cases.truth_problem(eq, mode, m)
+                tol = 3e-8 * max(1.0, (1000.0 / eq.n_nodes) ** 4)
+                for t in rng.choice(len(cand), size=min(2, len(cand)), replace=False):
+                    i, j = cand[int(t)]
+                    d, a_, b_, s_ = truth.mismatch(k[i], k[i] * W[j])
+                    if s_ != 0:
+                        continue
+                    e = abs(D[i, j] - d) / max(abs(a_), abs(b_))
+                    truth_n += 1
+                    truth_worst = max(truth_worst, e / tol)
+                    if e > tol:
+                        truth_bad += 1
+                        msg.append(f"DOP853 leg: |dD|/scale {e:.2e} > {tol:.1e} at k={k[i]:.4f} W={W[j]:.5f}")
         if msg:
             bad += 1
             print(f"case {c}: {type(eq).__name__} {eq} {mode} m={m}: " + "; ".join(msg), flush=True)
         gp.close()
     print(f"{n_cases} cases, {bad} failures, worst |dD|/scale {worst:.2e}")
+    if n_truth:
+        print(f"DOP853 leg: {truth_n} points of {min(n_truth, n_cases)} cases, {truth_bad} above the bound, worst error / bound {truth_worst:.3f}")
     return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 5))
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 5,
+                  int(sys.argv[3]) if len(sys.argv) > 3 else 0))
