@@ -627,8 +627,43 @@ struct RowBands {
   }
 };
 
+// per-row scalars of the flow slab in fp32 (KScal: k^2 c^2, k^2 vA^2, k^2 cT^2, k^4 cT^2 c^2; S_i)
+struct SlabScalF { float kc2, kvA2, kcT2, k4c, S; };
+
 template <int FAM, bool TRACK>
-__device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, v2f w, CoefPreF& C, ScreenF<TRACK>& sc) {
+__device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, v2f w, CoefPreF& C, ScreenF<TRACK>& sc,
+                                             const SlabScalF& ss) {
+  if (FAM == FAM_SLABD) {
+    // density slab (coef_pre<FAM_SLABD>): u' = v / F, v' = F m0 u; watched terms n1, n2, n3 (band family: the smallest
+    // of their magnitudes over the nodes says how close a coefficient came to a singular point)
+    const v2f w2 = w * w;
+    const v2f n1 = v2(e[0]) - w2, n2 = v2(e[1]) - w2, n3 = v2(e[2]) - w2;
+    sc.mn = vmin(sc.mn, vmin(vmin(vabs(n1), vabs(n2)), vabs(n3)));
+    C.n11 = v2(0.0f); C.n22 = v2(0.0f);
+    C.n12 = n1;
+    C.n21 = v2(e[4]) * n3;
+    C.den = v2(e[3]) * n2;
+    return;
+  }
+  if (FAM == FAM_SLABF) {
+    // flow slab (coef_pre<FAM_SLABF>): m0, D, coeff of SF-G:416-427 over the common denominator S t Om^2 n1; watched terms
+    // n1, t, n3 and Om (as Om^2, on the scale of the others)
+    const v2f Om = w - v2(e[0]);
+    const v2f Om2 = Om * Om;
+    const v2f t = Om2 - v2(ss.kcT2), n1 = v2(ss.kc2) - Om2, n3 = v2(ss.kvA2) - Om2;
+    sc.mn = vmin(sc.mn, vmin(vmin(vabs(n1), vabs(t)), vmin(vabs(n3), Om2)));
+    const v2f St = v2(ss.S) * t;
+    const v2f G = vfma(St, t, v2(ss.k4c));
+    const v2f X = Om * n1;
+    const v2f OX = Om * X;
+    const v2f g2 = v2(e[3]) * G;
+    C.n11 = v2(0.0f);
+    C.n12 = v2(1.0f);
+    C.n22 = g2 * Om;
+    C.n21 = -vfma(v2(e[2]), St * X, vfma(-g2, v2(e[1]), (n1 * n3) * OX));
+    C.den = St * OX;
+    return;
+  }
   const v2f Om = w - v2(e[0]);
   const v2f Om2 = Om * Om;
   const v2f t1 = Om2 - v2(e[1]);
@@ -667,6 +702,10 @@ template <int FAM>
 __device__ __forceinline__ void coef_finish_f32(const CoefPreF& C, v2f inv, CoefF& A) {
   if (FAM == FAM_CYL0) {
     A.a11 = v2(0.0f); A.a22 = v2(0.0f); A.a12 = C.n12; A.a21 = vfma(C.n21, inv, C.n22);
+  } else if (FAM == FAM_SLABD) {
+    A.a11 = v2(0.0f); A.a22 = v2(0.0f); A.a12 = C.n12 * inv; A.a21 = C.n21;
+  } else if (FAM == FAM_SLABF) {
+    A.a11 = v2(0.0f); A.a12 = v2(1.0f); A.a21 = C.n21 * inv; A.a22 = C.n22 * inv;
   } else {
     A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
   }
@@ -676,8 +715,9 @@ template <int FAM>
 __device__ __forceinline__ void rk4_step_adjoint_f32(v2f& p, v2f& q, const CoefF& B0, const CoefF& Bm, const CoefF& B1,
                                                      float h, float h2, float h6, float h3) {
 #define ES_RHS_TF(A, pp, qq, kp, kq)                                                            \
-  if (FAM == FAM_CYLT) { kp = vfma(A.a11, pp, A.a21 * qq); kq = vfma(A.a22, qq, A.a12 * pp); } \
-  else                 { kp = A.a21 * qq;                  kq = A.a12 * pp; }
+  if (FAM == FAM_CYLT)       { kp = vfma(A.a11, pp, A.a21 * qq); kq = vfma(A.a22, qq, A.a12 * pp); } \
+  else if (FAM == FAM_SLABF) { kp = A.a21 * qq;                  kq = vfma(A.a22, qq, pp); }         \
+  else                       { kp = A.a21 * qq;                  kq = A.a12 * pp; }
   v2f k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
   ES_RHS_TF(B0, p, q, k1p, k1q);
   tp = vfma(v2(h2), k1p, p); tq = vfma(v2(h2), k1q, q);
@@ -716,6 +756,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
     const int w0 = seg * T * PTS;
     const double k = kv[row];
     const KScal s = make_kscal(P, k);
+    const SlabScalF ss = {(float)s.kc2, (float)s.kvA2, (float)s.kcT2, (float)s.k4c, (float)P.S_i};
     v2f wf[NP], zp[NP], zq[NP];
     int zexp[PTS];                                     // accumulated power-of-two scaling of (zp, zq), per point
     CoefF B0[NP], B1[NP];
@@ -727,7 +768,8 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       const double w = (iw < nw) ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
       if (p & 1) wf[p >> 1].y = (float)w; else wf[p >> 1].x = (float)w;
       // m_e > 0 (evanescent exterior) and, for the band families, not inside a continuum band: worth a march
-      const double k2 = k * k, w2 = w * w;
+      const double Oe = (FAM == FAM_SLABD || FAM == FAM_SLABF) ? (w - k * P.U_e) : w;
+      const double k2 = k * k, w2 = Oe * Oe;
       const double m_e = ((k2 * P.vAe2 - w2) * (k2 * P.ce2 - w2)) / (P.Se * (k2 * P.cTe2 - w2));
       const bool dead = !TRACK && band_crossed(P, k, w);
       lane_live = lane_live || (iw < nw && m_e > 0.0 && !dead);
@@ -763,9 +805,10 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
           CoefPreF C;
-          coef_pre_f32<FAM, TRACK>(eL, P.c1_power, wf[p], C, scr[p]);
+          coef_pre_f32<FAM, TRACK>(eL, P.c1_power, wf[p], C, scr[p], ss);
           coef_finish_f32<FAM>(C, v2(1.0f) / C.den, B0[p]);
-          if (P.axis_bc == ES_AXIS_SAUSAGE) { zp[p] = B0[p].a11; zq[p] = B0[p].a12; } else { zp[p] = v2(1.0f); zq[p] = v2(0.0f); }
+          if ((FAM == FAM_CYL0 || FAM == FAM_CYLT) && P.axis_bc == ES_AXIS_SAUSAGE) { zp[p] = B0[p].a11; zq[p] = B0[p].a12; }
+          else { zp[p] = v2(1.0f); zq[p] = v2(0.0f); }
         }
       }
 #define ES_F32_STEP(J, BIN, BOUT)                                                                   \
@@ -777,8 +820,8 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
         }                                                                                           \
         _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                            \
           CoefPreF Cm, C1;                                                                          \
-          coef_pre_f32<FAM, TRACK>(em, P.c1_power, wf[p], Cm, scr[p]);                              \
-          coef_pre_f32<FAM, TRACK>(e1, P.c1_power, wf[p], C1, scr[p]);                              \
+          coef_pre_f32<FAM, TRACK>(em, P.c1_power, wf[p], Cm, scr[p], ss);                          \
+          coef_pre_f32<FAM, TRACK>(e1, P.c1_power, wf[p], C1, scr[p], ss);                          \
           const v2f inv = vrcp(Cm.den * C1.den);                                                    \
           CoefF Bm;                                                                                 \
           coef_finish_f32<FAM>(Cm, C1.den * inv, Bm);                                               \
@@ -846,6 +889,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       // (bc_const * xi_e, non-zero only for the twisted kink condition) is divided by it instead
       ShootDev Pl = P;
       Pl.bc_const = P.bc_const_raw * ldexp(1.0, -zexp[p]);
+      Pl.slab_sign = P.slab_sign * ldexp(1.0, -zexp[p]);          // slabs: (slab_sign - r1) / r2 with r = (r1, r2) 2^zexp
       const Mismatch M = boundary_algebra<FAM>(Pl, s, w, X, (double)zpp, (double)zqq, ef);
       // watched terms: certain sign / certain crossing / unsure (see ScreenF)
       const float S = F32_TAU_NODE * (float)(w * w + ef[1]);
@@ -853,10 +897,18 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       if (!TRACK) {                                     // band families: the status is exact (fp64 test on W = omega/k)
         crossed = band_crossed(P, k, w);
         const float mnp = hi_half ? sc.mn.y : sc.mn.x;
+        if (FAM == FAM_SLABD || FAM == FAM_SLABF) {
+          // slabs: the smallest magnitude of a watched term over the nodes against tau x the scale of these terms
+          // (omega^2 + k^2 c^2; the flow slab's omega is the Doppler-shifted one at the boundary)
+          const double Omb = (FAM == FAM_SLABF) ? (w - ef[0]) : w;
+          const float sz = (float)(Omb * Omb + ((FAM == FAM_SLABF) ? s.kc2 : ef[0]));
+          node_unsure = !crossed && !(mnp > F32_TAU_NODE * sz);
+        } else {
         // an evaluated point with a coefficient close to a singular point: |t1 t2| below tau (omega^2 + omega_A^2)^2 at
         // some node, i.e. ONE of the two factors within tau of zero relative to its size
         const float sz = (float)(w * w + ef[1]);
         node_unsure = !crossed && !(mnp > F32_TAU_NODE * sz * sz);
+        }
       } else {
         const float c3m = hi_half ? sc.c3m.y : sc.c3m.x;
         const int or3 = sc.or3[p & 1], and3 = sc.and3[p & 1];
@@ -891,7 +943,16 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       if (X.status == ES_PT_OK && crossed) {
         unsure = TRACK && !isfinite(M.d);               // fp64 reports ES_PT_NONFINITE before ES_PT_CONTINUUM: let it decide
       } else if (X.status == ES_PT_OK) {
-        const double scale = fmax(fabs(M.outer), fabs(M.inner));
+        double scale = fmax(fabs(M.outer), fabs(M.inner));
+        if (FAM == FAM_SLABD || FAM == FAM_SLABF) {
+          // slabs: the inner term is (slab_sign - r1) x ..., and r1 -- an element of the transfer matrix of an oscillating
+          // solution -- comes close to +-1: the fp32 error of r1 is then measured against the terms BEFORE the cancellation.
+          // The same algebra with the sign of slab_sign chosen so that nothing cancels gives that magnitude.
+          ShootDev Pb = Pl;
+          Pb.slab_sign = (zpp >= 0.0f) ? -fabs(Pl.slab_sign) : fabs(Pl.slab_sign);
+          const Mismatch Mb = boundary_algebra<FAM>(Pb, s, w, X, (double)zpp, (double)zqq, ef);
+          scale = fmax(scale, fabs(Mb.inner));
+        }
         unsure = node_unsure || !isfinite(M.d) || !(fabs(M.d) > F32_TAU_D * scale) ||
                  !(fabs(M.outer) > F32_TAU_POLE * fabs(M.inner));
       }
@@ -1600,8 +1661,24 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
     ES_HIP_CHECK(ctx, hipGetLastError());
     return ES_SUCCESS;
   } else {
-    ctx->last_error = "fp32 screening is implemented for the cylinder families";
-    return ES_ERR_UNSUPPORTED;
+    // slab families: band problems only (their status is exact from the phase speed; a profile whose node intervals do not
+    // overlap falls back to per-node tracking in fp64, which the fp32 pass has no counterpart of)
+    if (!prob->dev.use_bands) {
+      ctx->last_error = "fp32 screening of a slab needs connected continuum bands (per-node sign tracking: fp64 only)";
+      return ES_ERR_UNSUPPORTED;
+    }
+    es_timer_begin(ctx);
+    constexpr int PTS = 4;
+    int T = ((nw + PTS - 1) / PTS + 63) / 64 * 64;
+    if (T < 64) T = 64;
+    if (T > 256) T = 256;
+    const long tiles = (long)nk * ((nw + T * PTS - 1) / (T * PTS));
+    const int grid = (int)(tiles < (1L << 22) ? tiles : (1L << 22));
+    hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 3>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k,
+                       nk, d_w, nw, w_mode, d_D, d_status);
+    es_timer_end(ctx);
+    ES_HIP_CHECK(ctx, hipGetLastError());
+    return ES_SUCCESS;
   }
 }
 
@@ -1619,11 +1696,31 @@ int check_mixed_args(es_context* ctx, const es_problem* prob, int nk, int nw, in
   ES_REQUIRE(ctx, nk >= 0 && nw >= 0, "negative size");
   ES_REQUIRE(ctx, w_mode >= 0 && w_mode <= 2, "w_mode");
   const int fam = prob->dev.family;
-  if (fam != FAM_CYL0 && fam != FAM_CYLT) {
-    ctx->last_error = "fp32 screening is implemented for the cylinder families";
+  if (fam < FAM_CYL0 || fam > FAM_SLABF) return ES_ERR_UNSUPPORTED;
+  if ((fam == FAM_SLABD || fam == FAM_SLABF) && !prob->dev.use_bands) {
+    ctx->last_error = "fp32 screening of a slab needs connected continuum bands (per-node sign tracking: fp64 only)";
     return ES_ERR_UNSUPPORTED;
   }
   return ES_SUCCESS;
+}
+
+int launch_grid_f32_any(es_context* ctx, const es_problem* prob, const double* d_k, int nk, const double* d_w, int nw, int w_mode,
+                        double* d_D, uint8_t* d_status) {
+  switch (prob->dev.family) {
+    case FAM_CYL0: return launch_grid_f32<FAM_CYL0>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+    case FAM_CYLT: return launch_grid_f32<FAM_CYLT>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+    case FAM_SLABD: return launch_grid_f32<FAM_SLABD>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+    default: return launch_grid_f32<FAM_SLABF>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+  }
+}
+
+int points_any(es_context* ctx, const es_problem* prob, const double* pk, const double* pw, int n, double* pD, uint8_t* pst) {
+  switch (prob->dev.family) {
+    case FAM_CYL0: return points_into<FAM_CYL0>(ctx, prob, pk, pw, n, pD, pst);
+    case FAM_CYLT: return points_into<FAM_CYLT>(ctx, prob, pk, pw, n, pD, pst);
+    case FAM_SLABD: return points_into<FAM_SLABD>(ctx, prob, pk, pw, n, pD, pst);
+    default: return points_into<FAM_SLABF>(ctx, prob, pk, pw, n, pD, pst);
+  }
 }
 }  // namespace
 
@@ -1636,8 +1733,7 @@ extern "C" int es_shoot_screen_grid(es_context* ctx, const es_problem* prob, con
   if ((long)nk * nw == 0) return ES_SUCCESS;
   ES_REQUIRE(ctx, d_k && d_w && d_D && d_status, "null pointer");
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  return (prob->dev.family == FAM_CYL0) ? launch_grid_f32<FAM_CYL0>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status)
-                                        : launch_grid_f32<FAM_CYLT>(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
+  return launch_grid_f32_any(ctx, prob, d_k, nk, d_w, nw, w_mode, d_D, d_status);
 }
 
 extern "C" int es_shoot_find_roots_mixed(es_context* ctx, const es_problem* prob, const double* d_k, int nk,
@@ -1668,7 +1764,6 @@ extern "C" int es_shoot_find_roots_screened(es_context* ctx, const es_problem* p
   ES_REQUIRE(ctx, table->capacity == 0 || (table->d_k && table->d_w && table->d_w_lo && table->d_w_hi &&
                                            table->d_resid && table->d_row && table->d_flag),
              "null root table arrays");
-  const int fam = prob->dev.family;
   ES_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // 2. unsure points -> fp64
   rc = es_ensure_scan_scratch(ctx, (size_t)cells);
@@ -1697,8 +1792,7 @@ extern "C" int es_shoot_find_roots_screened(es_context* ctx, const es_problem* p
     hipLaunchKernelGGL(unsure_gather_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, d_k, d_w, nw, w_mode, cells,
                        ctx->d_masks, ctx->d_block_counts, pk, pw, pcell);
     ES_HIP_CHECK(ctx, hipGetLastError());
-    rc = (fam == FAM_CYL0) ? points_into<FAM_CYL0>(ctx, prob, pk, pw, n_unsure, pD, pst)
-                           : points_into<FAM_CYLT>(ctx, prob, pk, pw, n_unsure, pD, pst);
+    rc = points_any(ctx, prob, pk, pw, n_unsure, pD, pst);
     if (rc) return rc;
     hipLaunchKernelGGL(scatter_points_kernel, dim3((n_unsure + 255) / 256), dim3(256), 0, ctx->stream, pcell, pD, pst,
                        n_unsure, d_D, d_status);
@@ -1723,8 +1817,7 @@ extern "C" int es_shoot_find_roots_screened(es_context* ctx, const es_problem* p
     if (rc) return rc;
     hipLaunchKernelGGL(bracket_ends_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, *table, n, pk, pw);
     ES_HIP_CHECK(ctx, hipGetLastError());
-    rc = (fam == FAM_CYL0) ? points_into<FAM_CYL0>(ctx, prob, pk, pw, 2 * n, pD, pst)
-                           : points_into<FAM_CYLT>(ctx, prob, pk, pw, 2 * n, pD, pst);
+    rc = points_any(ctx, prob, pk, pw, 2 * n, pD, pst);
     if (rc) return rc;
     ES_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(bracket_ends_store_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pD, pst, n,

@@ -219,7 +219,9 @@ int es_shoot_find_roots_async(es_context* ctx, const es_problem* prob, const dou
                               int n_bisect, double tol_percent, es_root_table* table, int32_t* d_count);
 
 /* Mixed-precision grid search (BASELINE.json configs[4]: "fp32 bracket + fp64 refine"; the reference itself is fp64
- * throughout), for the cylinder families (ES_GEOM_CYLINDER, ES_GEOM_CYLINDER_TWIST).  What is GUARANTEED: every bracket
+ * throughout), for the cylinder families and (round 3) for the slab families whose continuum flag comes from phase-speed bands
+ * (every profile of the reference; a slab profile whose node intervals do not overlap needs per-node sign tracking, which
+ * exists in fp64 only: ES_ERR_UNSUPPORTED).  What is GUARANTEED: every bracket
  * it reports is an fp64 bracket (both ends re-evaluated in fp64, ES_ERR_SCREENING otherwise) and is refined exactly as
  * es_shoot_find_roots refines it.  What is EMPIRICAL: that no fp64 bracket is missed -- a sign change between two points
  * fp32 judged "sure" (|D| > 5e-2 of the scale, every watched coefficient term more than 1e-3 away from zero) would go

@@ -145,7 +145,9 @@ def test_round3_entry_points_reject_bad_arguments(es_ctx, monkeypatch):
     monkeypatch.delenv("ES_GRID_SHAPE")
     gp.eval_grid(k, W)
     # the halves of the mixed search: slabs are unsupported, the screened half needs table and count
+    monkeypatch.setenv("ES_FORCE_SIGN_TRACKING", "1")                  # a slab without bands: no fp32 screening
     gs = ShootProblem(q.SlabFlow(U_i0=0.35, width=1.5), "kink", ctx=es_ctx)
+    monkeypatch.delenv("ES_FORCE_SIGN_TRACKING")
     with pytest.raises(_lib.EsError, match="unsupported"):
         gs.screen_grid(k, W)
     Ds, ss = gp.screen_grid(k, W)
