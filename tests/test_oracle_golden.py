@@ -77,7 +77,12 @@ def _traces():
 
 @pytest.mark.parametrize("case", _traces())
 def test_oracle_vs_reference_trace(case):
+    """`<name>_conv`: the second trace set (tools/gen_golden.py --converge) -- the same calls with the reference's unconverged
+    fsolve calls re-solved to convergence on its own objective; there the evaluations whose slope the re-solve converged
+    (conv 1 / 5) are compared as well, which the first set has to skip (ier != 1)."""
     tr = json.load(open(os.path.join(G, f"trace_{case}.json")))
+    conv_set = case.endswith("_conv")
+    case = case[:-5] if conv_set else case
     n_cmp = n_full = 0
     worst_int = 0.0
     for call in tr["calls"]:
@@ -86,10 +91,12 @@ def test_oracle_vs_reference_trace(case):
         seen = set()
         for ev in call["evals"]:
             w, d = ev["omega"], ev["d"]
-            if w is None or d is None or not math.isfinite(d) or ev["ier"] != 1 or w in seen:
+            # second set: only what the first set had to skip -- evaluations whose slope the harness re-solved
+            converged = ev["ier"] == 1 if not conv_set else (ev.get("conv") in (1, 5) and (ev["ier"] != 1 or ev.get("conv") == 5))
+            if w is None or d is None or not math.isfinite(d) or not converged or w in seen:
                 continue
             seen.add(w)
-            if len(seen) > 14:            # enough per call; DOP853 is slow
+            if len(seen) > (8 if conv_set else 14):            # enough per call; DOP853 is slow
                 break
             ext = ev["ext_end"]
             if len(ext) == 4:            # odeintz (CR-*): complex state viewed as (re, im) pairs; im = 0
@@ -105,6 +112,9 @@ def test_oracle_vs_reference_trace(case):
             worst_int = max(worst_int, err)
             # LSODA runs the interior with atol = 1.5e-8 ABSOLUTE on a solution of size A = |y_e(boundary)|
             tol = max(3e-4, 40 * 1.5e-8 / A)
+            if conv_set and abs(a) <= tol * abs(b):
+                continue             # next to a pole of D (|outer| << |inner|: the refinement chains of the reference home in on
+                                     # them) the mismatch is 1 / (omega - omega_pole): no bound on its relative discrepancy
             assert err < tol, (case, call["fn"], k, w, do, d_ref, A)
             assert (do > 0) == (d_ref > 0) or abs(d_ref) < tol * scale     # determinant sign
             n_cmp += 1
@@ -121,6 +131,10 @@ def test_oracle_vs_reference_trace(case):
     # SD-C as checked in (dx = 0.9): every band between its `speeds` (SD-C:202) lies inside the Alfven / cusp continuum
     # of the profile (v_A rises from 1.2 to 1.71 towards the boundary) or has fsolve ier = 5: no evaluation is
     # comparable there, the determinant VALUES of that configuration are pinned through SDC_uniform only
+    print(f"{case}{'_conv' if conv_set else ''}: {n_cmp} evaluations compared (interior behind the reference's exterior), "
+          f"{n_full} with the closed-form exterior, worst interior discrepancy {worst_int:.2e} of the scale")
+    if conv_set:
+        return                       # the re-solved evaluations only: as many as the reference had left unconverged
     need = {"CRKF": 2, "SDC_w09": 0}.get(case, 6)
     assert n_cmp >= need, (case, n_cmp)
     assert n_full >= 1 or case.startswith(("SDP", "SDC", "SFU", "CRKF")), (case, n_full)
