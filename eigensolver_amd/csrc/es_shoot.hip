@@ -1056,6 +1056,9 @@ struct GridShape { int pts, wpe; };
 // exactly, 4 points x 128 lanes waste a quarter) and about not spilling; four points per lane share the LDS reads and
 // the loop overhead best.  WPE = 4 is used where the kernel fits 128 registers without a spill.
 template <int FAM> struct ShapeTable;
+// (three points per lane -- a row of 384 frequencies, configs[2], is 3 x 128 lanes exactly -- was measured too: 1.28 ms per
+// launch against 1.14 ms for 2 x 192: its two-wave workgroups hold 39 KB of LDS each, four fit a CU, two waves per SIMD;
+// wpe[3] = 0 keeps the shape out of the build)
 template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.14, 1.08, 0, 1.0}; };
 // twisted cylinder: equal speed at 1, 2 and 4 points per lane (517 issue cycles per point-step either way); two points per
 // lane need 212 registers, four would need 260 (256: a handful of values spilled around the exterior code)
@@ -1074,7 +1077,8 @@ template <int FAM>
 GridShape pick_shape(int nw, bool track) {
   GridShape best{4, 2};
   double best_cost = 1e300;
-  for (int pts : {4, 2, 1}) {
+  for (int pts : {4, 3, 2, 1}) {
+    if (ShapeTable<FAM>::wpe[pts] == 0) continue;      // not a shape of this family
     const int T = shape_threads(nw, pts);
     const long span = (long)T * pts;
     const long padded = (nw + span - 1) / span * span;
@@ -1086,7 +1090,7 @@ GridShape pick_shape(int nw, bool track) {
   if (track && fam_has_bands<FAM>()) best.wpe = 2;
   if (const char* ev = getenv("ES_GRID_SHAPE")) {
     int p = 0, w = 0;
-    if (sscanf(ev, "%d,%d", &p, &w) == 2 && (p == 1 || p == 2 || p == 4) && w >= 2 && w <= 4) best = GridShape{p, w};
+    if (sscanf(ev, "%d,%d", &p, &w) == 2 && p >= 1 && p <= 4 && w >= 2 && w <= 4) best = GridShape{p, w};
   }
   return best;
 }
@@ -1095,6 +1099,7 @@ GridShape pick_shape(int nw, bool track) {
 // (-DES_ALL_GRID_SHAPES, the measuring build of tools/probe/time_grid_shapes.py) everything ES_GRID_SHAPE can name
 template <int FAM, int PTS, int WPE, bool TRACK>
 constexpr bool shape_built() {
+  if (PTS == 3 && ShapeTable<FAM>::wpe[3] == 0) return false;
 #if defined(ES_ALL_GRID_SHAPES)
   return true;
 #else
@@ -1170,7 +1175,7 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
 #define ES_SHAPE(P_, W_)                                                                                            \
   one(integral_constant<int, P_>{}, integral_constant<int, W_>{}, integral_constant<bool, false>{});                \
   one(integral_constant<int, P_>{}, integral_constant<int, W_>{}, integral_constant<bool, true>{});
-  ES_SHAPE(4, 2) ES_SHAPE(4, 3) ES_SHAPE(4, 4) ES_SHAPE(2, 2) ES_SHAPE(2, 3) ES_SHAPE(2, 4) ES_SHAPE(1, 2) ES_SHAPE(1, 3) ES_SHAPE(1, 4)
+  ES_SHAPE(4, 2) ES_SHAPE(4, 3) ES_SHAPE(4, 4) ES_SHAPE(3, 2) ES_SHAPE(3, 3) ES_SHAPE(2, 2) ES_SHAPE(2, 3) ES_SHAPE(2, 4) ES_SHAPE(1, 2) ES_SHAPE(1, 3) ES_SHAPE(1, 4)
 #undef ES_SHAPE
   es_timer_end(ctx);
   if (!launched) {
