@@ -1216,7 +1216,8 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   // (ES_REFINE_SHARED_MIN); measured in round 3 with the count on the device (same box, tile of an E-GPU run, ms per
   // step shared / per-lane: E = 1 22.05 / 22.29, E = 2 11.35 / 11.28, E = 4 5.85 / 5.98, E = 8 3.19 / 3.29): no
   // crossover worth a rule, the shared form is the default at every count.  The twisted family (16 entries per node:
-  // 17 KB per wave at 16 steps per chunk, one workgroup per CU) lost 7 % on configs[4] and keeps per-lane entries.
+  // 17 KB per wave at 16 steps per chunk) lost 7 % on configs[4] in round 2 and, measured again with the cheaper round-3
+  // coefficient set (67.5 KB of LDS per workgroup, 181 VGPRs), 11 % (86.2 against 77.4 ms per step): per-lane entries stay.
   constexpr int CHR = (FAM == FAM_CYL0) ? 32 : 0;
   int shared_min = kSharedMin;
   if (const char* ev = getenv("ES_REFINE_SHARED_MIN")) shared_min = atoi(ev);
