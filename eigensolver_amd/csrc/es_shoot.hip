@@ -43,6 +43,18 @@ struct GridOpts {
   int main_span;
 };
 
+// ONE tile per workgroup, the launch has as many workgroups as tiles (es_tile_grid: the y dimension only counts beyond
+// 2^22 tiles).  The kernels are written as a loop over tiles that runs once: round 2 and most of round 3 launched at most
+// 2^22 workgroups and let each stride over the tiles -- a loop the compiler hoisted every tile-invariant value out of
+// (64-bit literals of the Bessel polynomials, kernel arguments, step sizes), and carried them in registers through the
+// march: 172 -> 103 VGPRs for the fp32 kernel of the untwisted cylinder, 286 -> 94 SGPRs spilled to lanes and no scratch
+// left in the twisted one once the loop was gone.
+constexpr long ES_TILE_GRID_X = 1L << 22;
+__device__ __forceinline__ long es_tile_index() { return (long)blockIdx.y * ES_TILE_GRID_X + blockIdx.x; }
+inline dim3 es_tile_grid(long tiles) {
+  return tiles <= ES_TILE_GRID_X ? dim3((unsigned)tiles) : dim3((unsigned)ES_TILE_GRID_X, (unsigned)((tiles + ES_TILE_GRID_X - 1) / ES_TILE_GRID_X));
+}
+
 template <int FAM, int PTS, int MAXT, bool TRACK, int WPE = 0>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
 void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
@@ -73,7 +85,7 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
   const int col_base = (opts.part == 2) ? (ncols / opts.main_span) * opts.main_span : 0;
   const int nseg = (opts.part == 2) ? opts.main_span / span : (nw + span - 1) / span;
   const long ntiles = (long)nk * nseg;
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (long tile = es_tile_index(), once = 1; once && tile < ntiles; once = 0) {
     // segment-major order: consecutive workgroup ids (dealt round-robin to the 8 XCDs) are consecutive k-rows of one
     // omega-segment.  With the row-major order tile = row * nseg + segment and nseg = 4, segment s of every row went to
     // XCDs s and s + 4: segments whose points are dead (continuum, leaky) or absent (compacted launch) idled two XCDs
@@ -630,8 +642,10 @@ struct RowBands {
 // per-row scalars of the flow slab in fp32 (KScal: k^2 c^2, k^2 vA^2, k^2 cT^2, k^4 cT^2 c^2; S_i)
 struct SlabScalF { float kc2, kvA2, kcT2, k4c, S; };
 
-template <int FAM, bool TRACK>
-__device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, v2f w, CoefPreF& C, ScreenF<TRACK>& sc,
+// C1P = c1_power of the twisted family as a template parameter: a runtime select between Om and Om^2 costs two
+// v_cndmask_b32 per pair and node (the kernel branches once per chunk instead).
+template <int FAM, bool TRACK, int C1P = 1>
+__device__ __forceinline__ void coef_pre_f32(const float* e, v2f w, CoefPreF& C, ScreenF<TRACK>& sc,
                                              const SlabScalF& ss) {
   if (FAM == FAM_SLABD) {
     // density slab (coef_pre<FAM_SLABD>): u' = v / F, v' = F m0 u; watched terms n1, n2, n3 (band family: the smallest
@@ -680,17 +694,22 @@ __device__ __forceinline__ void coef_pre_f32(const float* e, int c1_power, v2f w
     const v2f D = v2(e[3]) * t12;
     const v2f Q = vfma(Om, v2(e[7]), vfma(Om2, v2(e[6]), -(t1 * v2(e[5]))));
     const v2f T = vfma(v2(e[9]), Om, v2(e[8]));
-    const v2f OmP = (c1_power == 2) ? Om2 : Om;
+    const v2f OmP = (C1P == 2) ? Om2 : Om;
     const v2f t2T = t2 * T;
     const v2f C1 = vfma(Q, OmP, -(v2(e[10]) * t2T));
     const v2f C2 = vfma(Om2, Om2, -(v2(e[11]) * t2));
     const v2f c3a = D * vfma(v2(e[4]), t1, v2(e[12]));
     const v2f C3 = c3a + vfma(Q, Q, -(v2(e[13]) * t2T * T));
-    const v2f s3 = C3 * D;                              // sign of F = r D / C3, third watched term of the fp64 kernel
-    sc.or3[0] |= __float_as_int(s3.x); sc.and3[0] &= __float_as_int(s3.x);
-    sc.or3[1] |= __float_as_int(s3.y); sc.and3[1] &= __float_as_int(s3.y);
-    sc.c3m = vmin(sc.c3m, vfma(v2(-F32_TAU_NODE), vabs(c3a), vabs(C3)));
-    C.n11 = -C1;
+    // third watched term of the fp64 kernel: the sign of F = r D / C3, i.e. of C3 D.  A point is only vouched for when t1
+    // and t2 keep one sign over all nodes (RowBands), and e[3] = rho S > 0: D = e[3] t1 t2 then keeps its sign and C3 D
+    // changes sign exactly where C3 does -- the sign bits of C3 itself are tracked (no product per node).
+    sc.or3[0] |= __float_as_int(C3.x); sc.and3[0] &= __float_as_int(C3.x);
+    sc.or3[1] |= __float_as_int(C3.y); sc.and3[1] &= __float_as_int(C3.y);
+    // |C3| - tau |c3a| per component with the source modifiers of the unpacked v_fma_f32 (the packed form has no |x|
+    // modifier: four v_and_b32 and a v_pk_fma_f32 per pair and node)
+    sc.c3m.x = fminf(sc.c3m.x, fmaf(-F32_TAU_NODE, fabsf(c3a.x), fabsf(C3.x)));
+    sc.c3m.y = fminf(sc.c3m.y, fmaf(-F32_TAU_NODE, fabsf(c3a.y), fabsf(C3.y)));
+    C.n11 = v2(0.0f);                                   // a11 = -a22: not formed (rk4_step_adjoint_f32 negates a22)
     C.n22 = C1;
     C.n12 = C3 * v2(e[15]);
     C.n21 = -(v2(e[14]) * C2);
@@ -707,7 +726,7 @@ __device__ __forceinline__ void coef_finish_f32(const CoefPreF& C, v2f inv, Coef
   } else if (FAM == FAM_SLABF) {
     A.a11 = v2(0.0f); A.a12 = v2(1.0f); A.a21 = C.n21 * inv; A.a22 = C.n22 * inv;
   } else {
-    A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
+    A.a11 = v2(0.0f); A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;       // a11 = -a22
   }
 }
 
@@ -715,7 +734,7 @@ template <int FAM>
 __device__ __forceinline__ void rk4_step_adjoint_f32(v2f& p, v2f& q, const CoefF& B0, const CoefF& Bm, const CoefF& B1,
                                                      float h, float h2, float h6, float h3) {
 #define ES_RHS_TF(A, pp, qq, kp, kq)                                                            \
-  if (FAM == FAM_CYLT)       { kp = vfma(A.a11, pp, A.a21 * qq); kq = vfma(A.a22, qq, A.a12 * pp); } \
+  if (FAM == FAM_CYLT)       { kp = vfma(-A.a22, pp, A.a21 * qq); kq = vfma(A.a22, qq, A.a12 * pp); } \
   else if (FAM == FAM_SLABF) { kp = A.a21 * qq;                  kq = vfma(A.a22, qq, pp); }         \
   else                       { kp = A.a21 * qq;                  kq = A.a12 * pp; }
   v2f k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;
@@ -731,9 +750,87 @@ __device__ __forceinline__ void rk4_step_adjoint_f32(v2f& p, v2f& q, const CoefF
 #undef ES_RHS_TF
 }
 
-// The adjoint march renormalised: fp32 has 8 bits of exponent, an evanescent interior grows like e^{kappa (1 - r_ax)}
-// (1e30 and more at large k).  Both components are scaled by a power of two whenever they leave [2^-40, 2^40]; the
-// boundary algebra only uses the ratio r1 : r2 and the (rescaled) target of the axis condition.
+// One RK4 step of the fp32 march for the NP pairs of a lane.  `node` = the fp32 entries of node 2J in the LDS table,
+// those of the mid-point 2J + 1 follow NES floats later (node-major table: every entry of a step sits at a constant
+// offset from ONE uniform address -- ds_read_b128 with immediate offsets; the field-major table of round 2 needed a
+// base register of its own per field: 16 v_mov_b32 + 25 s_add_i32 per loop iteration of the twisted family).
+template <int FAM, int NP, bool TRACK, int C1P>
+__device__ __forceinline__ void f32_step(const float* node, const v2f* wf, v2f* zp, v2f* zq, const CoefF* BIN, CoefF* BOUT,
+                                         ScreenF<TRACK>* scr, const SlabScalF& ss, float h, float h2, float h6, float h3) {
+  constexpr int NE = FamTraits<FAM>::NE;
+  constexpr int NES = (NE + 3) & ~3;
+  float em[NE], e1[NE];
+#pragma unroll
+  for (int f = 0; f < NE; ++f) { e1[f] = node[f]; em[f] = node[NES + f]; }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    CoefPreF Cm, C1;
+    coef_pre_f32<FAM, TRACK, C1P>(em, wf[p], Cm, scr[p], ss);
+    coef_pre_f32<FAM, TRACK, C1P>(e1, wf[p], C1, scr[p], ss);
+    const v2f inv = vrcp(Cm.den * C1.den);
+    CoefF Bm;
+    coef_finish_f32<FAM>(Cm, C1.den * inv, Bm);
+    coef_finish_f32<FAM>(C1, Cm.den * inv, BOUT[p]);
+    rk4_step_adjoint_f32<FAM>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);
+  }
+}
+
+// The steps of one LDS chunk (nst of them, from the far end of the chunk towards the boundary).  The adjoint march is
+// renormalised: fp32 has 8 bits of exponent, an evanescent interior grows like e^{kappa (1 - r_ax)} (1e30 and more at
+// large k).  Both components are scaled by a power of two whenever they leave [2^-40, 2^40]; the boundary algebra only
+// uses the ratio r1 : r2 and the (rescaled) target of the axis condition.
+template <int FAM, int NP, bool TRACK, int C1P>
+__device__ __forceinline__ void f32_march_chunk(const float* lds, int nst, bool first, bool sausage_axis, const v2f* wf,
+                                                v2f* zp, v2f* zq, int* zexp, CoefF* B0, CoefF* B1, ScreenF<TRACK>* scr,
+                                                const SlabScalF& ss, float h, float h2, float h6, float h3) {
+  constexpr int NE = FamTraits<FAM>::NE;
+  constexpr int NES = (NE + 3) & ~3;
+  if (first) {                                         // far end of the march: coefficients of the last node, start values
+    float eL[NE];
+#pragma unroll
+    for (int f = 0; f < NE; ++f) eL[f] = lds[2 * nst * NES + f];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      CoefPreF C;
+      coef_pre_f32<FAM, TRACK, C1P>(eL, wf[p], C, scr[p], ss);
+      coef_finish_f32<FAM>(C, v2(1.0f) / C.den, B0[p]);
+      if ((FAM == FAM_CYL0 || FAM == FAM_CYLT) && sausage_axis) {
+        zp[p] = (FAM == FAM_CYLT) ? -B0[p].a22 : B0[p].a11;
+        zq[p] = B0[p].a12;
+      } else { zp[p] = v2(1.0f); zq[p] = v2(0.0f); }
+    }
+  }
+  // steps in pairs with the roles of B0 / B1 swapped (no coefficient copies); CH is even, so only the last chunk of an
+  // odd march has a single leading step
+  int j = nst - 1;
+  if (nst & 1) {
+    f32_step<FAM, NP, TRACK, C1P>(lds + 2 * j * NES, wf, zp, zq, B0, B1, scr, ss, h, h2, h6, h3);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) B0[p] = B1[p];
+    --j;
+  }
+  for (; j >= 1; j -= 2) {
+    f32_step<FAM, NP, TRACK, C1P>(lds + 2 * j * NES, wf, zp, zq, B0, B1, scr, ss, h, h2, h6, h3);
+    f32_step<FAM, NP, TRACK, C1P>(lds + 2 * (j - 1) * NES, wf, zp, zq, B1, B0, scr, ss, h, h2, h6, h3);
+    if (((j - 1) & 31) == 0) {                         // renormalise every 32 steps
+#pragma unroll
+      for (int p = 0; p < 2 * NP; ++p) {
+        float a = (p & 1) ? zp[p >> 1].y : zp[p >> 1].x;
+        float b = (p & 1) ? zq[p >> 1].y : zq[p >> 1].x;
+        const float mag = fmaxf(fabsf(a), fabsf(b));
+        if (mag > 1.0995116e12f || (mag < 9.094947e-13f && mag > 0.0f)) {       // outside [2^-40, 2^40]
+          int ex;
+          (void)frexpf(mag, &ex);
+          a = ldexpf(a, -ex);
+          b = ldexpf(b, -ex);
+          zexp[p] += ex;
+          if (p & 1) { zp[p >> 1].y = a; zq[p >> 1].y = b; } else { zp[p >> 1].x = a; zq[p >> 1].x = b; }
+        }
+      }
+    }
+  }
+}
+
 // The closed-form exterior (fp64 Bessel code, ~100 VGPRs) is evaluated AFTER the march, when the loop state is dead;
 // before the march only the sign of m_e is needed to know which lanes have something to march.
 template <int FAM, int PTS, int MAXT, bool TRACK, int WPE>
@@ -743,14 +840,14 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
   static_assert(PTS % 2 == 0, "points are processed in pairs");
   constexpr int NP = PTS / 2;
   constexpr int NE = FamTraits<FAM>::NE;
-  constexpr int LSTRIDE = 2 * CH + 1;
-  __shared__ float lds[NE * LSTRIDE];
+  constexpr int NES = (NE + 3) & ~3;                   // floats per node in the LDS table (16-byte rows)
+  __shared__ __align__(16) float lds[NES * (2 * CH + 1)];
   const int T = blockDim.x;
   const int nsteps = P.n_nodes - 1;
   const float h = (float)P.h, h2 = (float)(0.5 * P.h), h6 = (float)(P.h / 6.0), h3 = (float)(P.h / 3.0);
   const int nseg = (nw + T * PTS - 1) / (T * PTS);
   const long ntiles = (long)nk * nseg;
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (long tile = es_tile_index(), once = 1; once && tile < ntiles; once = 0) {
     const int seg = (int)(tile / nk);                  // segment-major, as in shoot_grid_kernel (XCD balance)
     const int row = (int)(tile - (long)seg * nk);
     const int w0 = seg * T * PTS;
@@ -780,6 +877,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
     const bool wave_live = __any(lane_live);
     const bool wg_live = __syncthreads_or(wave_live ? 1 : 0) != 0;
     const int nchunks = wg_live ? (nsteps + CH - 1) / CH : 0;
+    const bool sausage_axis = P.axis_bc == ES_AXIS_SAUSAGE;
     RowBands bands;
     for (int c = nchunks - 1; c >= 0; --c) {
       const int c0 = c * CH;
@@ -789,8 +887,12 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
         double b[FamTraits<FAM>::NB], e[NE];
         load_base<FAM>(P, 2 * c0 + i, b);
         make_entry<FAM>(b, s, e);                      // fp64, rounded to fp32 once
+        float ef32[NES];
 #pragma unroll
-        for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = (float)e[f];
+        for (int f = 0; f < NES; ++f) ef32[f] = (f < NE) ? (float)e[f] : 0.0f;
+#pragma unroll
+        for (int f = 0; f < NES; f += 4)
+          *reinterpret_cast<float4*>(&lds[i * NES + f]) = make_float4(ef32[f], ef32[f + 1], ef32[f + 2], ef32[f + 3]);
         if (TRACK) {                                   // where t1 / t2 are negative at this node: omega within a of e0
           bands.add(0, e[0], sqrt(e[1]));
           bands.add(1, e[0], sqrt(e[2]));
@@ -798,69 +900,17 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       }
       __syncthreads();
       if (!wave_live) continue;
-      if (c == nchunks - 1) {
-        float eL[NE];
-#pragma unroll
-        for (int f = 0; f < NE; ++f) eL[f] = lds[f * LSTRIDE + 2 * nst];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          CoefPreF C;
-          coef_pre_f32<FAM, TRACK>(eL, P.c1_power, wf[p], C, scr[p], ss);
-          coef_finish_f32<FAM>(C, v2(1.0f) / C.den, B0[p]);
-          if ((FAM == FAM_CYL0 || FAM == FAM_CYLT) && P.axis_bc == ES_AXIS_SAUSAGE) { zp[p] = B0[p].a11; zq[p] = B0[p].a12; }
-          else { zp[p] = v2(1.0f); zq[p] = v2(0.0f); }
-        }
-      }
-#define ES_F32_STEP(J, BIN, BOUT)                                                                   \
-      {                                                                                             \
-        float em[NE], e1[NE];                                                                       \
-        _Pragma("unroll") for (int f = 0; f < NE; ++f) {                                            \
-          em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                                   \
-          e1[f] = lds[f * LSTRIDE + 2 * (J)];                                                       \
-        }                                                                                           \
-        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                            \
-          CoefPreF Cm, C1;                                                                          \
-          coef_pre_f32<FAM, TRACK>(em, P.c1_power, wf[p], Cm, scr[p], ss);                          \
-          coef_pre_f32<FAM, TRACK>(e1, P.c1_power, wf[p], C1, scr[p], ss);                          \
-          const v2f inv = vrcp(Cm.den * C1.den);                                                    \
-          CoefF Bm;                                                                                 \
-          coef_finish_f32<FAM>(Cm, C1.den * inv, Bm);                                               \
-          coef_finish_f32<FAM>(C1, Cm.den * inv, BOUT[p]);                                          \
-          rk4_step_adjoint_f32<FAM>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);              \
-        }                                                                                           \
-      }
-      // steps in pairs with the roles of B0 / B1 swapped (no coefficient copies); CH is even, so only the last chunk
-      // of an odd march has a single leading step
-      int j = nst - 1;
-      if (nst & 1) {
-        ES_F32_STEP(j, B0, B1)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) B0[p] = B1[p];
-        --j;
-      }
-      for (; j >= 1; j -= 2) {
-        ES_F32_STEP(j, B0, B1)
-        ES_F32_STEP(j - 1, B1, B0)
-        if (((j - 1) & 31) == 0) {                     // renormalise every 32 steps
-#pragma unroll
-          for (int p = 0; p < PTS; ++p) {
-            float a = (p & 1) ? zp[p >> 1].y : zp[p >> 1].x;
-            float b = (p & 1) ? zq[p >> 1].y : zq[p >> 1].x;
-            const float mag = fmaxf(fabsf(a), fabsf(b));
-            if (mag > 1.0995116e12f || (mag < 9.094947e-13f && mag > 0.0f)) {       // outside [2^-40, 2^40]
-              int ex;
-              (void)frexpf(mag, &ex);
-              a = ldexpf(a, -ex);
-              b = ldexpf(b, -ex);
-              zexp[p] += ex;
-              if (p & 1) { zp[p >> 1].y = a; zq[p >> 1].y = b; } else { zp[p >> 1].x = a; zq[p >> 1].x = b; }
-            }
-          }
-        }
-      }
-#undef ES_F32_STEP
+      if (FAM == FAM_CYLT && P.c1_power == 2)
+        f32_march_chunk<FAM, NP, TRACK, 2>(lds, nst, c == nchunks - 1, sausage_axis, wf, zp, zq, zexp, B0, B1, scr, ss, h, h2, h6, h3);
+      else
+        f32_march_chunk<FAM, NP, TRACK, 1>(lds, nst, c == nchunks - 1, sausage_axis, wf, zp, zq, zexp, B0, B1, scr, ss, h, h2, h6, h3);
     }
     if (TRACK && wg_live) bands.reduce(lds, T);        // workgroup-uniform condition (the reduction has barriers)
+    // the exterior code below needs products of k the prologue has already formed (k^2 vA_e^2, ...): reused, they would
+    // sit in registers across the whole march -- and did not fit (five spilled doubles per lane, 10 MB of scratch writes
+    // per launch).  An opaque copy of k makes the compiler form them again here.
+    double kx = k;
+    asm volatile("" : "+v"(kx));
     double bf[FamTraits<FAM>::NB], ef[NE];
     load_base<FAM>(P, 0, bf);
     make_entry<FAM>(bf, s, ef);
@@ -879,8 +929,8 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
     for (int p = 0; p < PTS; ++p) {
       const int iw = w0 + p * T + (int)threadIdx.x;
       if (iw >= nw) continue;
-      const double w = pick_w(wv, w_mode, k, row, nw, iw);
-      const ExteriorLite X = exterior_lite(P, k, w, w);
+      const double w = pick_w(wv, w_mode, kx, row, nw, iw);
+      const ExteriorLite X = exterior_lite(P, kx, w, w);
       const bool hi_half = (p & 1);
       const ScreenF<TRACK>& sc = scr[p >> 1];
       const float zpp = hi_half ? zp[p >> 1].y : zp[p >> 1].x;
@@ -895,7 +945,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       const float S = F32_TAU_NODE * (float)(w * w + ef[1]);
       bool crossed, node_unsure;
       if (!TRACK) {                                     // band families: the status is exact (fp64 test on W = omega/k)
-        crossed = band_crossed(P, k, w);
+        crossed = band_crossed(P, kx, w);
         const float mnp = hi_half ? sc.mn.y : sc.mn.x;
         if (FAM == FAM_SLABD || FAM == FAM_SLABF) {
           // slabs: the smallest magnitude of a watched term over the nodes against tau x the scale of these terms
@@ -1059,12 +1109,18 @@ template <int FAM> struct ShapeTable;
 // (three points per lane -- a row of 384 frequencies, configs[2], is 3 x 128 lanes exactly -- was measured too: 1.28 ms per
 // launch against 1.14 ms for 2 x 192: its two-wave workgroups hold 39 KB of LDS each, four fit a CU, two waves per SIMD;
 // wpe[3] = 0 keeps the shape out of the build)
-template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.14, 1.08, 0, 1.0}; };
-// twisted cylinder: equal speed at 1, 2 and 4 points per lane (517 issue cycles per point-step either way); two points per
-// lane need 212 registers, four would need 260 (256: a handful of values spilled around the exterior code)
-template <> struct ShapeTable<FAM_CYLT>  { static constexpr int wpe[5] = {0, 3, 2, 0, 2}; static constexpr double cost[5] = {0, 1.02, 1.0, 0, 1.01}; };
-template <> struct ShapeTable<FAM_SLABD> { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.14, 1.09, 0, 1.0}; };
-template <> struct ShapeTable<FAM_SLABF> { static constexpr int wpe[5] = {0, 3, 3, 0, 3}; static constexpr double cost[5] = {0, 1.11, 1.06, 0, 1.0}; };
+// (measured again after the kernels became one tile per workgroup -- es_tile_index -- which freed 40 - 90 registers per
+// shape: profiles/r3e_grid_shapes.json, ms per launch, best register cap per point count)
+//   untwisted cylinder 1024 x 4096: 4 pts 5.03 (wpe 3), 2 pts 5.14, 1 pt 5.46; 4096 x 384: 2 pts x 192 lanes 1.27 (wpe 4; 1.32
+//   at wpe 3), 4 pts x 128 lanes 1.80
+template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 4, 0, 3}; static constexpr double cost[5] = {0, 1.09, 1.025, 0, 1.0}; };
+// twisted cylinder 1024 x 1024, N = 2000: 4 pts 6.60 (200 registers, two workgroups per CU), 2 pts 6.70, 1 pt 6.85 (7.8 - 8.2
+// for every shape while the tile loop was there)
+template <> struct ShapeTable<FAM_CYLT>  { static constexpr int wpe[5] = {0, 3, 2, 0, 2}; static constexpr double cost[5] = {0, 1.04, 1.015, 0, 1.0}; };
+// density slab 1024 x 1024: 4 pts 1.45 (wpe 3), 2 pts 1.62 (wpe 4), 1 pt 1.75 (wpe 4)
+template <> struct ShapeTable<FAM_SLABD> { static constexpr int wpe[5] = {0, 4, 4, 0, 3}; static constexpr double cost[5] = {0, 1.20, 1.12, 0, 1.0}; };
+// flow slab 1024 x 1024: 4 pts 1.28 (wpe 3), 2 pts 1.25 (wpe 4), 1 pt 1.33 (wpe 2): within the noise of one another
+template <> struct ShapeTable<FAM_SLABF> { static constexpr int wpe[5] = {0, 2, 4, 0, 3}; static constexpr double cost[5] = {0, 1.04, 1.0, 0, 1.0}; };
 
 inline int shape_threads(int nw, int pts) {
   int T = ((nw + pts - 1) / pts + 63) / 64 * 64;
@@ -1144,7 +1200,7 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   GridShape shape = pick_shape<FAM>(nw, track);
   const int T = shape_threads(nw, shape.pts);
   const long tiles = (long)nk * ((nw + (long)T * shape.pts - 1) / ((long)T * shape.pts));
-  const int grid = (int)(tiles < (1L << 22) ? tiles : (1L << 22));
+  const dim3 grid = es_tile_grid(tiles);
   bool launched = false;
   es_timer_begin(ctx);
   auto one = [&](auto pts_c, auto wpe_c, auto track_c) {
@@ -1157,17 +1213,17 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
         if (opts.cols && T > 64) {
           // compacted launch: full segments in 4-wave workgroups, the remainder of each row in one-wave workgroups
           opts.part = 1;
-          hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, 256, TRACK, WPE>), dim3(grid), dim3(T), 0, ctx->stream,
+          hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, 256, TRACK, WPE>), grid, dim3(T), 0, ctx->stream,
                              prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
           opts.part = 2;
           opts.main_span = 4 * T;
           const long tiles2 = (long)nk * (T / 64);
-          hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 64, false, 2>), dim3((int)(tiles2 < (1L << 22) ? tiles2 : (1L << 22))),
+          hipLaunchKernelGGL((shoot_grid_kernel<FAM, 4, 64, false, 2>), es_tile_grid(tiles2),
                              dim3(64), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
           return;
         }
       }
-      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, 256, TRACK, WPE>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev,
+      hipLaunchKernelGGL((shoot_grid_kernel<FAM, PTS, 256, TRACK, WPE>), grid, dim3(T), 0, ctx->stream, prob->dev,
                          d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
     }
   };
@@ -1618,30 +1674,30 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
     if (T < 64) T = 64;
     if (T > 256) T = 256;
     const long tiles = (long)nk * ((nw + T * PTS - 1) / (T * PTS));
-    const int grid = (int)(tiles < (1L << 22) ? tiles : (1L << 22));
+    const dim3 grid = es_tile_grid(tiles);
     const bool bands = fam_has_bands<FAM>() && prob->dev.use_bands;
     // register caps: 128 VGPRs (4 waves per SIMD) for the untwisted family, 168 (3 waves) for the twisted one
     if constexpr (FAM == FAM_CYL0) {
       int v0 = 0;
       if (const char* ev = getenv("ES_F32_VARIANT")) v0 = atoi(ev);             // tuning aid
       if (bands && v0 == 1)
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 3>), dim3(grid), dim3(T), 0, ctx->stream,
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 3>), grid, dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       else if (bands && v0 == 2)
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 2>), dim3(grid), dim3(T), 0, ctx->stream,
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 2>), grid, dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       else if (bands && v0 == 3) {
         int T8 = ((nw + 7) / 8 + 63) / 64 * 64;
         if (T8 < 64) T8 = 64;
         if (T8 > 256) T8 = 256;
         const long t8 = (long)nk * ((nw + T8 * 8 - 1) / (T8 * 8));
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, 8, 256, false, 2>), dim3((int)(t8 < (1L << 22) ? t8 : (1L << 22))),
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, 8, 256, false, 2>), es_tile_grid(t8),
                            dim3(T8), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       } else if (bands)
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 4>), dim3(grid), dim3(T), 0, ctx->stream,
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 4>), grid, dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       else
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 4>), dim3(grid), dim3(T), 0, ctx->stream,
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 4>), grid, dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
     } else {
       // measured on configs[4] (1024^2, N = 2000), packed fp32: 4 points per lane at 2 waves per SIMD (no spills) 4.5 ms;
@@ -1649,17 +1705,17 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
       int variant = 1;
       if (const char* ev = getenv("ES_F32_VARIANT")) variant = atoi(ev);        // tuning aid
       if (variant == 1) {
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 2>), dim3(grid), dim3(T), 0, ctx->stream,
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 2>), grid, dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       } else if (variant == 2) {
         int T2 = ((nw + 1) / 2 + 63) / 64 * 64;
         if (T2 < 64) T2 = 64;
         if (T2 > 256) T2 = 256;
         const long tiles2 = (long)nk * ((nw + T2 * 2 - 1) / (T2 * 2));
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, 2, 256, true, 4>), dim3((int)(tiles2 < (1L << 22) ? tiles2 : (1L << 22))),
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, 2, 256, true, 4>), es_tile_grid(tiles2),
                            dim3(T2), 0, ctx->stream, prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       } else {
-        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 3>), dim3(grid), dim3(T), 0, ctx->stream,
+        hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, true, 3>), grid, dim3(T), 0, ctx->stream,
                            prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_status);
       }
     }
@@ -1679,8 +1735,8 @@ int launch_grid_f32(es_context* ctx, const es_problem* prob, const double* d_k, 
     if (T < 64) T = 64;
     if (T > 256) T = 256;
     const long tiles = (long)nk * ((nw + T * PTS - 1) / (T * PTS));
-    const int grid = (int)(tiles < (1L << 22) ? tiles : (1L << 22));
-    hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 3>), dim3(grid), dim3(T), 0, ctx->stream, prob->dev, d_k,
+    const dim3 grid = es_tile_grid(tiles);
+    hipLaunchKernelGGL((shoot_grid_f32_kernel<FAM, PTS, 256, false, 3>), grid, dim3(T), 0, ctx->stream, prob->dev, d_k,
                        nk, d_w, nw, w_mode, d_D, d_status);
     es_timer_end(ctx);
     ES_HIP_CHECK(ctx, hipGetLastError());

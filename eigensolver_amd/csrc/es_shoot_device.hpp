@@ -267,7 +267,9 @@ __device__ __forceinline__ void coef_finish(const CoefPre& C, double inv, Coef& 
   if (FAM == FAM_CYL0) {
     A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12; A.a21 = fma(C.n21, inv, C.n22);
   } else if (FAM == FAM_CYLT) {
-    A.a11 = C.n11 * inv; A.a22 = C.n22 * inv; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
+    // n11 = -n22: a11 = (-C1) inv = -(C1 inv) bit for bit -- one product, the negation rides on the source modifier of
+    // the fma that uses it
+    A.a22 = C.n22 * inv; A.a11 = -A.a22; A.a12 = C.n12 * inv; A.a21 = C.n21 * inv;
   } else if (FAM == FAM_SLABD) {
     A.a11 = 0.0; A.a22 = 0.0; A.a12 = C.n12 * inv; A.a21 = C.n21;
   } else {
@@ -324,7 +326,7 @@ template <int SHAPE>
 __device__ __forceinline__ void rk4_step_adjoint(double& p, double& q, const Coef& B0, const Coef& Bm, const Coef& B1,
                                                  double h, double h2, double h6, double h3) {
 #define ES_RHS_T(A, pp, qq, kp, kq)                                                          \
-  if (SHAPE == 1)      { kp = fma(A.a11, pp, A.a21 * qq); kq = fma(A.a22, qq, A.a12 * pp); } \
+  if (SHAPE == 1)      { kp = fma(-A.a22, pp, A.a21 * qq); kq = fma(A.a22, qq, A.a12 * pp); } /* a11 = -a22 */ \
   else if (SHAPE == 2) { kp = A.a21 * qq;                 kq = fma(A.a22, qq, pp); }         \
   else                 { kp = A.a21 * qq;                 kq = A.a12 * pp; }
   double k1p, k1q, k2p, k2q, k3p, k3q, k4p, k4q, tp, tq;

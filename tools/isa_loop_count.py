@@ -101,7 +101,9 @@ def march_loop(insns, rcp_class="rcp_f64"):
     inner = [r for r in regions if not any(o != r and o[0] >= r[0] and o[1] <= r[1] for o in regions)]
     if not inner:
         return None
-    lo, hi = max(inner, key=lambda r: r[1] - r[0])
+    # the march loop reads a whole row of node entries per step: of the candidates, the one with the most LDS reads (a loop
+    # of the exterior code that touches the LDS stash once qualifies otherwise)
+    lo, hi = max(inner, key=lambda r: (sum(1 for _, m, _ in insns[r[0]:r[1] + 1] if m.startswith("ds_read")), r[1] - r[0]))
     return insns[lo:hi + 1]
 
 
