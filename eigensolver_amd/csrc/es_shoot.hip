@@ -420,7 +420,7 @@ constexpr int REFINE_WAVES = 4;
 // shared by the LANES lanes of the bracket (shoot_point_wavegroup); CHR = 0: every lane forms its own (shoot_point).
 // SECTIONS_ONLY (n_polish < 0, what launch_refine uses whenever there is a section round): no status is needed from the
 // evaluations (shoot_point<FAM, false>).
-template <int FAM, int LANES, int CHR = 0, bool SECTIONS_ONLY = false, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+template <int FAM, int LANES, int CHR = 0, bool SECTIONS_ONLY = false, bool ONE = false, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n, int n_max,
                    int n_rounds, int n_polish, double tol_percent) {                      // d_lo / d_hi alias table columns
@@ -447,8 +447,13 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, co
   // copy keeps the kernel at the register footprint of the point kernel plus the bracket state, so that refinement
   // waves fit beside the grid kernel's when consecutive steps are pipelined over two streams)
   const int n_final = (n_polish > 0) ? n_polish : (n_polish == 0 ? 1 : 0);
-  for (int it = 0; it < n_rounds + n_final; ++it) {
-    const bool section = it < n_rounds;
+  // ONE: a single section round per launch (the host launches the kernel n_rounds times; lo / hi / D(lo) / D(hi) travel
+  // through the table columns, the same doubles).  A loop over rounds around the inlined determinant evaluation lets the
+  // compiler hoist every round-invariant value of that code -- 64-bit literals of the Bessel polynomials, kernel
+  // arguments -- out of it and carry them through the march (see es_tile_index).
+  const int n_it = ONE ? 1 : n_rounds + n_final;
+  for (int it = 0; it < n_it; ++it) {
+    const bool section = ONE ? true : it < n_rounds;
     double x;
     if (section) {
       x = lo + (hi - lo) * frac;
@@ -499,9 +504,11 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, co
 
 // The polish steps of refine_kernel with ONE lane per bracket (same arithmetic, bit for bit): in refine_kernel all LANES
 // lanes of a bracket evaluate the same secant point, so two of its six marches do a sixteenth of the work they cost.
-template <int FAM, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+// ONE: a single polish step per launch (see refine_kernel), `n_polish` = 1 on the last of them, 0 before: the bracket and D
+// at its ends go back to the columns they came from until the last step writes root, residual and flag.
+template <int FAM, bool ONE = false, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void refine_polish_kernel(ShootDev P, es_root_table tab, const double* d_lo, const double* d_hi, const int* __restrict__ d_n,
+void refine_polish_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n,
                           int n_max, int n_polish, double tol_percent) {   // d_lo / d_hi alias table columns (no restrict)
   ES_POINT_LDS(FAM);
   const int n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
@@ -515,7 +522,8 @@ void refine_polish_kernel(ShootDev P, es_root_table tab, const double* d_lo, con
   double fhi = in ? d_hi[i] : -1.0;
   double D = 0.0, rel = 0.0; uint8_t st = 0;
   double root = lo;
-  for (int it = 0; it < n_polish; ++it) {
+  const int n_it = ONE ? 1 : n_polish;
+  for (int it = 0; it < n_it; ++it) {
     double x = lo - flo * (hi - lo) / (fhi - flo);
     if (!(x > lo && x < hi)) x = (x == x) ? ((fabs(flo) <= fabs(fhi)) ? lo : hi) : lo + (hi - lo) * 0.5;
     shoot_point<FAM>(P, k, x, x, D, rel, st, es_point_lds);
@@ -523,11 +531,16 @@ void refine_polish_kernel(ShootDev P, es_root_table tab, const double* d_lo, con
     if (D * flo < 0.0) { hi = x; fhi = D; } else if (D == D) { lo = x; flo = D; }
   }
   if (in) {
-    tab.d_w[i] = root;
     tab.d_w_lo[i] = lo;
     tab.d_w_hi[i] = hi;
-    tab.d_resid[i] = rel;
-    tab.d_flag[i] = (st == ES_PT_OK && rel < tol_percent) ? 1 : 0;
+    if (ONE && n_polish == 0) {                        // not the last step: state for the next launch
+      d_lo[i] = flo;
+      d_hi[i] = fhi;
+    } else {
+      tab.d_w[i] = root;
+      tab.d_resid[i] = rel;
+      tab.d_flag[i] = (st == ES_PT_OK && rel < tol_percent) ? 1 : 0;
+    }
   }
 }
 
@@ -1279,9 +1292,23 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   if (const char* ev = getenv("ES_REFINE_SHARED_MIN")) shared_min = atoi(ev);
   const bool shared_entries = CHR > 0 && np < 0 && n_hint >= shared_min && !getenv("ES_REFINE_PRIVATE_ENTRIES");
   auto blocks = [&](int per_wg) { return dim3((n_max + per_wg - 1) / per_wg); };
+  // One section round / polish step per launch for the twisted family (refine_kernel: 255 -> 194 registers; configs[4]
+  // 74.2 -> 72.6 ms per step on one box).  Measured for the others too, registers 167 -> 102: no gain on configs[2] and [3]
+  // (7.58 / 7.58, 20.81 / 20.82 ms), a loss on configs[1] (2.92 -> 3.05 ms: six short launches per search instead of two);
+  // a register cap of 168 for the twisted kernels (three waves per SIMD, 14 - 18 spilled values) made no difference
+  // (72.4 / 72.6).  ES_REFINE_ROUNDS_IN_KERNEL=1: the single launch (A/B aid).
+  constexpr bool ONE_ROUND_FAM = (FAM == FAM_CYLT);
+  const bool one_round = ONE_ROUND_FAM && !getenv("ES_REFINE_ROUNDS_IN_KERNEL");
 #define ES_REFINE(LANES_, CHR_, SO_, PER_WG_)                                                                           \
-  hipLaunchKernelGGL((refine_kernel<FAM, LANES_, CHR_, SO_>), blocks(PER_WG_), dim3(64 * REFINE_WAVES), 0, ctx->stream, \
-                     prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol)
+  if (SO_ && one_round) {                                                                                               \
+    if constexpr (ONE_ROUND_FAM && SO_) {                                                                               \
+      for (int r_ = 0; r_ < rounds; ++r_)                                                                               \
+        hipLaunchKernelGGL((refine_kernel<FAM, LANES_, CHR_, true, true>), blocks(PER_WG_), dim3(64 * REFINE_WAVES), 0, \
+                           ctx->stream, prob->dev, tab, d_lo, d_hi, d_n, n_max, 1, np, tol);                            \
+    }                                                                                                                   \
+  } else                                                                                                                \
+    hipLaunchKernelGGL((refine_kernel<FAM, LANES_, CHR_, SO_, false>), blocks(PER_WG_), dim3(64 * REFINE_WAVES), 0,     \
+                       ctx->stream, prob->dev, tab, d_lo, d_hi, d_n, n_max, rounds, np, tol)
   if (sections == 17 && shared_entries) ES_REFINE(16, CHR, true, 4 * REFINE_WAVES);       // shared entries imply np < 0
   else if (np < 0) {
     if (sections == 17) ES_REFINE(16, 0, true, 4 * REFINE_WAVES);
@@ -1295,8 +1322,15 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
 #undef ES_REFINE
   ES_HIP_CHECK(ctx, hipGetLastError());
   if (np < 0) {
-    hipLaunchKernelGGL((refine_polish_kernel<FAM>), blocks(64 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
-                       prob->dev, tab, d_lo, d_hi, d_n, n_max, ES_REFINE_POLISH, tol);
+    if (one_round) {
+      if constexpr (ONE_ROUND_FAM) {
+        for (int p_ = 0; p_ < ES_REFINE_POLISH; ++p_)
+          hipLaunchKernelGGL((refine_polish_kernel<FAM, true>), blocks(64 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                             prob->dev, tab, d_lo, d_hi, d_n, n_max, p_ == ES_REFINE_POLISH - 1 ? 1 : 0, tol);
+      }
+    } else
+      hipLaunchKernelGGL((refine_polish_kernel<FAM, false>), blocks(64 * REFINE_WAVES), dim3(64 * REFINE_WAVES), 0, ctx->stream,
+                         prob->dev, tab, d_lo, d_hi, d_n, n_max, ES_REFINE_POLISH, tol);
     ES_HIP_CHECK(ctx, hipGetLastError());
   }
   return ES_SUCCESS;

@@ -19,7 +19,8 @@ go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
 for f in glob.glob(os.path.join(go, f"prof_stats_{tag}{suf}", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(pr, f"{tag}_{stem}_kernel_stats.csv"))
-shutil.copy(os.path.join(go, f"bench_{tag}{suf}.json"), os.path.join(pr, f"{tag}_{stem}_line.json"))
+if os.path.exists(os.path.join(go, f"bench_{tag}{suf}.json")):      # absent on the first pass of tools/profile_bench.sh (PMC summary before the line)
+    shutil.copy(os.path.join(go, f"bench_{tag}{suf}.json"), os.path.join(pr, f"{tag}_{stem}_line.json"))
 out = {}
 for name in ("fetch", "write", "sq"):
     for f in glob.glob(os.path.join(go, f"prof_{name}_{tag}{suf}", "*", "*_counter_collection.csv")):
