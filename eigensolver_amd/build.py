@@ -77,6 +77,7 @@ def build(force=False, verbose=False):
     # ES_BUILD_ALL_SHAPES=1: the measuring build of tools/probe/time_grid_shapes.py -- every (points per lane, waves per
     # SIMD) launch shape of the grid kernel that ES_GRID_SHAPE can name, not only the ones the tables select
     extra = ["-DES_ALL_GRID_SHAPES"] if os.environ.get("ES_BUILD_ALL_SHAPES") == "1" else []
+    extra += os.environ.get("ES_BUILD_EXTRA_FLAGS", "").split()          # experiments (-D...)
     if force or needs_build(LIB):
         _compile_and_link(LIB, extra, "", verbose)
     if force or needs_build(LIB_IEEE):

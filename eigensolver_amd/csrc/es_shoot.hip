@@ -187,8 +187,45 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
             adjoint_step<FAM>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);                             \
           }                                                                                 \
         }
+        // two RK4 steps of all PTS points with ONE division per point (coefficients4: families with fam_rcp4()): nodes
+        // 2J+1, 2J (step J) and 2J-1, 2J-2 (step J-1); start coefficients BIN, end coefficients of step J-1 to BOUT
+#define ES_MARCH_PAIR(J, BIN, BOUT)                                                         \
+        {                                                                                   \
+          double em[NE], e1[NE], em2[NE], e12[NE];                                          \
+          _Pragma("unroll") for (int f = 0; f < NE; ++f) {                                  \
+            em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                         \
+            e1[f] = lds[f * LSTRIDE + 2 * (J)];                                             \
+            em2[f] = lds[f * LSTRIDE + 2 * (J) - 1];                                        \
+            e12[f] = lds[f * LSTRIDE + 2 * (J) - 2];                                        \
+          }                                                                                 \
+          _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                 \
+            Coef Bm, Bj, Bm2;                                                               \
+            coefficients4<FAM, TRACK>(em, e1, em2, e12, P, s, w[p], Bm, Bj, Bm2, BOUT[p], trk[p]); \
+            adjoint_step<FAM>(zp[p], zq[p], BIN[p], Bm, Bj, h, h2, h6, h3);                 \
+            adjoint_step<FAM>(zp[p], zq[p], Bj, Bm2, BOUT[p], h, h2, h6, h3);               \
+          }                                                                                 \
+        }
         int j = nst - 1;
-        if (PAIR) {
+        if (fam_rcp4<FAM>()) {
+          // step j with step j - 1 for every odd j (the pairing every fp64 march of the family uses: coefficients4); an
+          // even top step alone; the pairs two per iteration with the roles of B0 / B1 swapped (no coefficient copies)
+          if (nst & 1) {
+            ES_MARCH_STEP(j, B0, B1)
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+            --j;
+          }
+          if (((j + 1) >> 1) & 1) {                    // odd number of pairs: one ahead of the loop
+            ES_MARCH_PAIR(j, B0, B1)
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+            j -= 2;
+          }
+          for (; j >= 3; j -= 4) {
+            ES_MARCH_PAIR(j, B0, B1)
+            ES_MARCH_PAIR(j - 2, B1, B0)
+          }
+        } else if (PAIR) {
           // steps in pairs with the roles of B0 / B1 swapped, so that no coefficient is copied between iterations
           if (nst & 1) {
             ES_MARCH_STEP(j, B0, B1)
@@ -207,6 +244,7 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
             for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
           }
         }
+#undef ES_MARCH_PAIR
 #undef ES_MARCH_STEP
 #pragma unroll
         for (int p = 0; p < PTS; ++p) adjoint_rescale<FAM>(zp[p], zq[p], nsteps - c0 - nst, nsteps - c0);
@@ -420,7 +458,8 @@ constexpr int REFINE_WAVES = 4;
 // shared by the LANES lanes of the bracket (shoot_point_wavegroup); CHR = 0: every lane forms its own (shoot_point).
 // SECTIONS_ONLY (n_polish < 0, what launch_refine uses whenever there is a section round): no status is needed from the
 // evaluations (shoot_point<FAM, false>).
-template <int FAM, int LANES, int CHR = 0, bool SECTIONS_ONLY = false, bool ONE = false, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+template <int FAM, int LANES, int CHR = 0, bool SECTIONS_ONLY = false, bool ONE = false,
+          int WPE = ((FAM == FAM_CYLT || (FAM == FAM_CYL0 && !ONE)) ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n, int n_max,
                    int n_rounds, int n_polish, double tol_percent) {                      // d_lo / d_hi alias table columns
@@ -506,7 +545,7 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, co
 // lanes of a bracket evaluate the same secant point, so two of its six marches do a sixteenth of the work they cost.
 // ONE: a single polish step per launch (see refine_kernel), `n_polish` = 1 on the last of them, 0 before: the bracket and D
 // at its ends go back to the columns they came from until the last step writes root, residual and flag.
-template <int FAM, bool ONE = false, int WPE = (FAM == FAM_CYLT ? 2 : 3)>
+template <int FAM, bool ONE = false, int WPE = ((FAM == FAM_CYLT || (FAM == FAM_CYL0 && !ONE)) ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_polish_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n,
                           int n_max, int n_polish, double tol_percent) {   // d_lo / d_hi alias table columns (no restrict)
@@ -1126,7 +1165,7 @@ template <int FAM> struct ShapeTable;
 // shape: profiles/r3e_grid_shapes.json, ms per launch, best register cap per point count)
 //   untwisted cylinder 1024 x 4096: 4 pts 5.03 (wpe 3), 2 pts 5.14, 1 pt 5.46; 4096 x 384: 2 pts x 192 lanes 1.27 (wpe 4; 1.32
 //   at wpe 3), 4 pts x 128 lanes 1.80
-template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 4, 0, 3}; static constexpr double cost[5] = {0, 1.09, 1.025, 0, 1.0}; };
+template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.09, 1.025, 0, 1.0}; };
 // twisted cylinder 1024 x 1024, N = 2000: 4 pts 6.60 (200 registers, two workgroups per CU), 2 pts 6.70, 1 pt 6.85 (7.8 - 8.2
 // for every shape while the tile loop was there)
 template <> struct ShapeTable<FAM_CYLT>  { static constexpr int wpe[5] = {0, 3, 2, 0, 2}; static constexpr double cost[5] = {0, 1.04, 1.015, 0, 1.0}; };
@@ -1297,7 +1336,7 @@ int launch_refine(es_context* ctx, const es_problem* prob, const es_root_table& 
   // (7.58 / 7.58, 20.81 / 20.82 ms), a loss on configs[1] (2.92 -> 3.05 ms: six short launches per search instead of two);
   // a register cap of 168 for the twisted kernels (three waves per SIMD, 14 - 18 spilled values) made no difference
   // (72.4 / 72.6).  ES_REFINE_ROUNDS_IN_KERNEL=1: the single launch (A/B aid).
-  constexpr bool ONE_ROUND_FAM = (FAM == FAM_CYLT);
+  constexpr bool ONE_ROUND_FAM = (FAM == FAM_CYLT || FAM == FAM_CYL0);
   const bool one_round = ONE_ROUND_FAM && !getenv("ES_REFINE_ROUNDS_IN_KERNEL");
 #define ES_REFINE(LANES_, CHR_, SO_, PER_WG_)                                                                           \
   if (SO_ && one_round) {                                                                                               \

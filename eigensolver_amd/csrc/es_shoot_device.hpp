@@ -316,6 +316,39 @@ __device__ __forceinline__ void coefficients2(const double* em, const double* e1
   coef_finish<FAM>(C1, Cm.den * inv, A1);
 }
 
+// four nodes of TWO consecutive RK4 steps (mid-point and end-point of each) with one division: the product tree
+//   d12 = den_m den_1, d34 = den_m' den_1', inv = 1 / (d12 d34), 1/d12 = d34 inv, 1/d34 = d12 inv, 1/den_m = den_1 (1/d12), ...
+// costs 9 multiplications and one reciprocal (v_rcp_f64, quarter rate, + its 3-fma correction) per two steps where two
+// coefficients2 cost 6 and two: half a reciprocal less per point-step (152.5 -> 144.5 issue cycles for the untwisted
+// cylinder; same-box A/B of the headline 20.5 -> 19.8 ms per step).  Every fp64 march of a family with fam_rcp4() pairs
+// its steps the same way -- step j with step j - 1 for every ODD j, counted from the boundary (j = 0); an even top step
+// (odd number of steps) is taken alone -- so that the grid kernels, the point kernels (chunks of CH or CHR steps: both
+// even) and the CPU port produce the same bits.  The four denominators are products of two watched terms each; their
+// product stays far inside the fp64 range (|t| <= ~1e4 in the reference's units, >= 1e-300 only at a flagged point).
+#if defined(ES_NO_RCP4)                                // A/B build (timing only: the CPU port pairs the steps)
+template <int FAM> constexpr bool fam_rcp4() { return false; }
+#else
+template <int FAM> constexpr bool fam_rcp4() { return FAM == FAM_CYL0; }
+#endif
+
+template <int FAM, bool TRACK = true>
+__device__ __forceinline__ void coefficients4(const double* em, const double* e1, const double* em2, const double* e12,
+                                              const ShootDev& P, const KScal& s, double w, Coef& Am, Coef& A1, Coef& Am2,
+                                              Coef& A12, SignTrack& st) {
+  CoefPre Cm, C1, Cn, C2;
+  coef_pre<FAM, TRACK>(em, P, s, w, Cm, st);
+  coef_pre<FAM, TRACK>(e1, P, s, w, C1, st);
+  coef_pre<FAM, TRACK>(em2, P, s, w, Cn, st);
+  coef_pre<FAM, TRACK>(e12, P, s, w, C2, st);
+  const double d12 = Cm.den * C1.den, d34 = Cn.den * C2.den;
+  const double inv = fast_rcp(d12 * d34);
+  const double i12 = d34 * inv, i34 = d12 * inv;
+  coef_finish<FAM>(Cm, C1.den * i12, Am);
+  coef_finish<FAM>(C1, Cm.den * i12, A1);
+  coef_finish<FAM>(Cn, C2.den * i34, Am2);
+  coef_finish<FAM>(C2, Cn.den * i34, A12);
+}
+
 // ---- one RK4 step of the ADJOINT (row-vector) propagation -----------------------------------------------------
 // Only one row of the interior transfer matrix T is needed (the axis / symmetry condition is one linear functional
 // of the state at the far end).  With M the RK4 step matrix from node j to j+1, M^T is the RK4 step of the

@@ -92,18 +92,68 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
       coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
       adjoint_start(P, B0, zp, zq);
     }
-    for (int j = nst - 1; j >= 0; --j) {
-      Coef Bm, B1;
-#pragma unroll
-      for (int f = 0; f < NB; ++f) b[f] = sb[(2 * j + 1) * NB + f];
-      make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
-#pragma unroll
-      for (int f = 0; f < NB; ++f) b[f] = sb[2 * j * NB + f];
-      make_entry<FAM, fam_scaled<FAM>()>(b, s, e2);
-      coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
-      adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
-      B0 = B1;
+    // The coefficients of a step (of a pair of steps: fam_rcp4) are formed one iteration AHEAD of the RK4 stages that use
+    // them: they depend on the node and on omega only, not on the marched row, so a lone wave -- these kernels run one or
+    // two per SIMD -- has the entries, the division and the products of the next step to issue while the dependent fma
+    // chain of this step's stages waits for its results.  Same operations on the same values as the grid kernel.
+#define ES_ENTRY(NODE, E)                                                                      \
+    {                                                                                          \
+      _Pragma("unroll") for (int f = 0; f < NB; ++f) b[f] = sb[(NODE) * NB + f];               \
+      make_entry<FAM, fam_scaled<FAM>()>(b, s, E);                                             \
     }
+    int j = nst - 1;
+    if (fam_rcp4<FAM>()) {
+      if (!(j & 1)) {                                  // even top step (odd number of steps): alone
+        Coef Bm, B1;
+        ES_ENTRY(2 * j + 1, e)
+        ES_ENTRY(2 * j, e2)
+        coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
+        adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+        B0 = B1;
+        --j;
+      }
+      if (j >= 1) {                                    // steps j and j - 1 with one division (coefficients4)
+        double e1[NE], em2[NE];
+        Coef Cm, C1, Cm2, C2;
+        ES_ENTRY(2 * j + 1, e)
+        ES_ENTRY(2 * j, e1)
+        ES_ENTRY(2 * j - 1, em2)
+        ES_ENTRY(2 * j - 2, e2)
+        coefficients4<FAM, TRACK>(e, e1, em2, e2, P, s, w, Cm, C1, Cm2, C2, trk);
+        for (; j >= 3; j -= 2) {
+          Coef Nm, N1, Nm2, N2;
+          ES_ENTRY(2 * j - 3, e)
+          ES_ENTRY(2 * j - 4, e1)
+          ES_ENTRY(2 * j - 5, em2)
+          ES_ENTRY(2 * j - 6, e2)
+          coefficients4<FAM, TRACK>(e, e1, em2, e2, P, s, w, Nm, N1, Nm2, N2, trk);
+          adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
+          adjoint_step<FAM>(zp, zq, C1, Cm2, C2, h, h2, h6, h3);
+          B0 = C2;
+          Cm = Nm; C1 = N1; Cm2 = Nm2; C2 = N2;
+        }
+        adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
+        adjoint_step<FAM>(zp, zq, C1, Cm2, C2, h, h2, h6, h3);
+        B0 = C2;
+      }
+    } else {
+      Coef Cm, C1;
+      ES_ENTRY(2 * j + 1, e)
+      ES_ENTRY(2 * j, e2)
+      coefficients2<FAM, TRACK>(e, e2, P, s, w, Cm, C1, trk);
+      for (; j >= 1; --j) {
+        Coef Nm, N1;
+        ES_ENTRY(2 * j - 1, e)
+        ES_ENTRY(2 * j - 2, e2)
+        coefficients2<FAM, TRACK>(e, e2, P, s, w, Nm, N1, trk);
+        adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
+        B0 = C1;
+        Cm = Nm; C1 = N1;
+      }
+      adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
+      B0 = C1;
+    }
+#undef ES_ENTRY
     adjoint_rescale<FAM>(zp, zq, nsteps - c0 - nst, nsteps - c0);   // steps marched before / after this chunk
   }
   const Mismatch M = boundary_algebra<FAM>(P, s, w, X, zp, zq, e2);
@@ -164,13 +214,47 @@ __device__ __forceinline__ void shoot_point_wavegroup_impl(const ShootDev& P, do
       coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
       adjoint_start(P, B0, zp, zq);
     }
-    for (int j = nst - 1; j >= 0; --j) {
-      Coef Bm, B1;
+    int j = nst - 1;
+    if (!fam_rcp4<FAM>() || !(j & 1)) {
+      // one step at a time; with fam_rcp4() only an even top step (odd number of steps) is taken this way
+      for (; j >= 0 && (!fam_rcp4<FAM>() || !(j & 1)); --j) {
+        Coef Bm, B1;
 #pragma unroll
-      for (int f = 0; f < NE; ++f) { e[f] = mine[(2 * j + 1) * NE + f]; e2[f] = mine[2 * j * NE + f]; }
-      coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
-      adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
-      B0 = B1;
+        for (int f = 0; f < NE; ++f) { e[f] = mine[(2 * j + 1) * NE + f]; e2[f] = mine[2 * j * NE + f]; }
+        coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
+        adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
+        B0 = B1;
+      }
+    }
+    if (fam_rcp4<FAM>() && j >= 1) {
+      // steps j and j - 1 with one division (coefficients4, as shoot_point_impl: same values), and the coefficients of a
+      // pair formed one iteration AHEAD of the two RK4 steps that use them: they depend on the node and on omega only, not
+      // on the marched row, so a lone wave -- a refinement launch has one or two per SIMD -- has the division of the next
+      // pair to issue while the dependent fma chain of this pair's RK4 stages waits for its results
+      double e1[NE], em2[NE];
+      Coef Cm, C1, Cm2, C2;
+#pragma unroll
+      for (int f = 0; f < NE; ++f) {
+        e[f] = mine[(2 * j + 1) * NE + f]; e1[f] = mine[2 * j * NE + f];
+        em2[f] = mine[(2 * j - 1) * NE + f]; e2[f] = mine[(2 * j - 2) * NE + f];
+      }
+      coefficients4<FAM, TRACK>(e, e1, em2, e2, P, s, w, Cm, C1, Cm2, C2, trk);
+      for (; j >= 3; j -= 2) {
+        Coef Nm, N1, Nm2, N2;
+#pragma unroll
+        for (int f = 0; f < NE; ++f) {
+          e[f] = mine[(2 * j - 3) * NE + f]; e1[f] = mine[(2 * j - 4) * NE + f];
+          em2[f] = mine[(2 * j - 5) * NE + f]; e2[f] = mine[(2 * j - 6) * NE + f];
+        }
+        coefficients4<FAM, TRACK>(e, e1, em2, e2, P, s, w, Nm, N1, Nm2, N2, trk);
+        adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
+        adjoint_step<FAM>(zp, zq, C1, Cm2, C2, h, h2, h6, h3);
+        B0 = C2;
+        Cm = Nm; C1 = N1; Cm2 = Nm2; C2 = N2;
+      }
+      adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
+      adjoint_step<FAM>(zp, zq, C1, Cm2, C2, h, h2, h6, h3);
+      B0 = C2;
     }
     adjoint_rescale<FAM>(zp, zq, nsteps - c0 - nst, nsteps - c0);
   }

@@ -357,6 +357,24 @@ static void coefficients2(const port_problem* P, const double* em, const double*
   coef_finish(P, &C1, Cm.den * inv, A1);
 }
 
+/* mid-point and end-point of TWO consecutive steps with a single division (coefficients4 of the HIP header: the product
+   tree d12 = den_m den_1, d34 = den_m' den_1', inv = 1 / (d12 d34), 1/d12 = d34 inv, 1/d34 = d12 inv) */
+static void coefficients4(const port_problem* P, const double* em, const double* e1, const double* em2, const double* e12,
+                          const kscal* s, double w, coef* Am, coef* A1, coef* Am2, coef* A12, strack* st) {
+  coefpre Cm, C1, Cn, C2;
+  coef_pre(P, em, s, w, &Cm, st);
+  coef_pre(P, e1, s, w, &C1, st);
+  coef_pre(P, em2, s, w, &Cn, st);
+  coef_pre(P, e12, s, w, &C2, st);
+  const double d12 = Cm.den * C1.den, d34 = Cn.den * C2.den;
+  const double inv = 1.0 / (d12 * d34);
+  const double i12 = d34 * inv, i34 = d12 * inv;
+  coef_finish(P, &Cm, C1.den * i12, Am);
+  coef_finish(P, &C1, Cm.den * i12, A1);
+  coef_finish(P, &Cn, C2.den * i34, Am2);
+  coef_finish(P, &C2, Cn.den * i34, A12);
+}
+
 /* adjoint right-hand side A^T z and one RK4 step of the row-vector march (see rk4_step_adjoint in the HIP header) */
 static inline void rhs_t(int diag, const coef* A, double p, double q, double* kp, double* kq) {
   if (diag) { *kp = fma(A->a11, p, A->a21 * q); *kq = fma(A->a22, q, A->a12 * p); }
@@ -489,12 +507,27 @@ static int port_eval_core(const port_problem* P, double k, double w, double w_cs
   coefficients(P, e, &s, w, &B0, tp);
   if (P->family <= 1 && P->axis_bc == ES_AXIS_SAUSAGE) { zp = B0.a11; zq = B0.a12; } else { zp = 1.0; zq = 0.0; }
   for (int j = nsteps - 1; j >= 0; --j) {
+    if (P->family == 0 && (j & 1)) {
+      /* fam_rcp4 of the HIP header: step j with step j - 1 for every odd j, one division for both (an even top step alone) */
+      double e1[16], em2[16];
+      coef Bm2, B2;
+      make_entry(P, 2 * j + 1, &s, e);
+      make_entry(P, 2 * j, &s, e1);
+      make_entry(P, 2 * j - 1, &s, em2);
+      make_entry(P, 2 * j - 2, &s, e2);
+      coefficients4(P, e, e1, em2, e2, &s, w, &Bm, &B1, &Bm2, &B2, tp);
+      rk4_adjoint_scaled0(&zp, &zq, &B0, &Bm, &B1);
+      rk4_adjoint_scaled0(&zp, &zq, &B1, &Bm2, &B2);
+      B0 = B2;
+      --j;                                             /* two steps taken: j is now the even step of the pair */
+    } else {
     make_entry(P, 2 * j + 1, &s, e);
     make_entry(P, 2 * j, &s, e2);
     coefficients2(P, e, e2, &s, w, &Bm, &B1, tp);
     if (P->family == 0) rk4_adjoint_scaled0(&zp, &zq, &B0, &Bm, &B1);
     else rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
     B0 = B1;
+    }
     if (P->family == 0 && j % PORT_CH == 0) {          /* end of an LDS chunk of the HIP march: adjoint_rescale */
       const int nst = (nsteps - j < PORT_CH) ? (nsteps - j) : PORT_CH;
       const int ex = port_rescale_exp(nsteps - j - nst, nsteps - j);

@@ -30,7 +30,7 @@ def test_no_spill_inside_a_march_loop(built):
     for name, v in loops.items():
         if name.startswith("shoot_grid_kernel"):
             assert v["scratch_in_loop"] == 0, (name, v["scratch_in_loop"])
-            assert v["point_steps_per_iteration"] in (1, 2, 4, 8), (name, v["point_steps_per_iteration"])
+            assert v["point_steps_per_iteration"] in (1, 2, 4, 8, 16), (name, v["point_steps_per_iteration"])
     # whole-kernel spill counts of the fp64 grid shapes: none since the kernels process one tile per workgroup (the tile
     # loop of rounds 2 - 3 carried hoisted tile-invariant values through the march: 168 registers + 6 spilled values for
     # the headline shape, 123 and none without it)
@@ -51,6 +51,6 @@ def test_isa_loop_counts_file_is_current(built):
     for k in loops:
         assert committed[k]["per_point_step"] == pytest.approx(loops[k]["per_point_step"]), k
         assert committed[k]["issue_cycles_per_wave_point_step"] == pytest.approx(loops[k]["issue_cycles_per_wave_point_step"]), k
-    # the headline loop: 34 fp64 instructions (23 of them fma) + one v_rcp_f64 per point and RK4 step
+    # the headline loop: 34 fp64 instructions + HALF a v_rcp_f64 per point and RK4 step (two steps share a division)
     h = loops["shoot_grid_kernel<0,4,256,false,3>"]["per_point_step"]
-    assert h["fp64"] + h["fp64_fma"] == pytest.approx(34.0) and h["rcp_f64"] == pytest.approx(1.0)
+    assert h["fp64"] + h["fp64_fma"] == pytest.approx(34.0) and h["rcp_f64"] == pytest.approx(0.5)

@@ -3,7 +3,8 @@
     python tools/isa_loop_count.py [--write]      (--write: profiles/isa_loop_counts.json, read by bench.py)
 
 The march loop of a kernel = the innermost backward-branch region that contains LDS reads (the node entries) and
-v_rcp_f64 (ONE reciprocal per point and RK4 step: their number in the loop body is points x steps per iteration).
+v_rcp_f64 (ONE reciprocal per point and RK4 step -- per point and TWO steps for the untwisted cylinder since its marches
+share a division between two steps: their number in the loop body gives points x steps per iteration).
 Per point-step: fp64 VALU instructions (4 issue cycles per wave on gfx950: 16 lanes per cycle), v_rcp_f64 (quarter
 rate: 16 cycles), other VALU (4), LDS reads (issued through the same port; counted, priced at 0 in `issue_cycles`),
 scalar / wait instructions.  bench.py prices a launch with it:  issue_cycles x (points / 64) x steps / 1024 SIMDs
@@ -128,7 +129,9 @@ def conditional_block(body):
     return skipped
 
 
-def count(body, rcp_class="rcp_f64"):
+def count(body, rcp_class="rcp_f64", steps_per_rcp=1):
+    """steps_per_rcp: RK4 steps of a point that share one reciprocal (2 for the fp64 marches of the untwisted cylinder,
+    fam_rcp4 in csrc/es_shoot_device.hpp: coefficients4)."""
     c = {}
     cond = conditional_block(body)
     cond_cycles = 0.0
@@ -137,7 +140,7 @@ def count(body, rcp_class="rcp_f64"):
         c[k] = c.get(k, 0) + 1
         if a in cond and (k.startswith(("fp64", "packed", "f32", "valu")) or k.startswith("rcp")):
             cond_cycles += 16.0 if k.startswith("rcp") else 4.0
-    n = c.get(rcp_class, 0)
+    n = c.get(rcp_class, 0) * steps_per_rcp
     per = {k: v / n for k, v in c.items()}
     # issue cycles per wave and point-step: fp64 / packed fp32 / other VALU 4, quarter-rate reciprocals 16
     cyc = 4.0 * sum(per.get(k, 0) for k in ("fp64", "fp64_fma", "packed_f32", "packed_f32_fma", "f32", "f32_fma", "valu_other")) + \
@@ -160,7 +163,7 @@ def table():
         if short.startswith("shoot_grid_kernel"):
             body = march_loop(ks[mangled])
             if body:
-                out[short] = count(body)
+                out[short] = count(body, steps_per_rcp=2 if short.startswith("shoot_grid_kernel<0,") else 1)
         elif short.startswith("shoot_grid_f32_kernel"):
             body = march_loop(ks[mangled], "rcp_f32")
             if body:
