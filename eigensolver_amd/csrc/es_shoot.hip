@@ -215,15 +215,25 @@ void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
             for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
             --j;
           }
-          if (((j + 1) >> 1) & 1) {                    // odd number of pairs: one ahead of the loop
-            ES_MARCH_PAIR(j, B0, B1)
+          if (TRACK && FAM != FAM_CYL0) {
+            // the sign-tracking fall-backs of the slab families (profiles whose continuum intervals do not overlap) keep
+            // three or four watched terms per point: one pair per iteration (two would not fit 256 registers)
+            for (; j >= 1; j -= 2) {
+              ES_MARCH_PAIR(j, B0, B1)
 #pragma unroll
-            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
-            j -= 2;
-          }
-          for (; j >= 3; j -= 4) {
-            ES_MARCH_PAIR(j, B0, B1)
-            ES_MARCH_PAIR(j - 2, B1, B0)
+              for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+            }
+          } else {
+            if (((j + 1) >> 1) & 1) {                  // odd number of pairs: one ahead of the loop
+              ES_MARCH_PAIR(j, B0, B1)
+#pragma unroll
+              for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
+              j -= 2;
+            }
+            for (; j >= 3; j -= 4) {
+              ES_MARCH_PAIR(j, B0, B1)
+              ES_MARCH_PAIR(j - 2, B1, B0)
+            }
           }
         } else if (PAIR) {
           // steps in pairs with the roles of B0 / B1 swapped, so that no coefficient is copied between iterations
@@ -459,7 +469,7 @@ constexpr int REFINE_WAVES = 4;
 // SECTIONS_ONLY (n_polish < 0, what launch_refine uses whenever there is a section round): no status is needed from the
 // evaluations (shoot_point<FAM, false>).
 template <int FAM, int LANES, int CHR = 0, bool SECTIONS_ONLY = false, bool ONE = false,
-          int WPE = ((FAM == FAM_CYLT || (FAM == FAM_CYL0 && !ONE)) ? 2 : 3)>
+          int WPE = ((FAM == FAM_CYLT || !ONE) ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n, int n_max,
                    int n_rounds, int n_polish, double tol_percent) {                      // d_lo / d_hi alias table columns
@@ -545,7 +555,7 @@ void refine_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, co
 // lanes of a bracket evaluate the same secant point, so two of its six marches do a sixteenth of the work they cost.
 // ONE: a single polish step per launch (see refine_kernel), `n_polish` = 1 on the last of them, 0 before: the bracket and D
 // at its ends go back to the columns they came from until the last step writes root, residual and flag.
-template <int FAM, bool ONE = false, int WPE = ((FAM == FAM_CYLT || (FAM == FAM_CYL0 && !ONE)) ? 2 : 3)>
+template <int FAM, bool ONE = false, int WPE = ((FAM == FAM_CYLT || !ONE) ? 2 : 3)>
 __global__ __launch_bounds__(64 * REFINE_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void refine_polish_kernel(ShootDev P, es_root_table tab, double* d_lo, double* d_hi, const int* __restrict__ d_n,
                           int n_max, int n_polish, double tol_percent) {   // d_lo / d_hi alias table columns (no restrict)

@@ -325,10 +325,11 @@ __device__ __forceinline__ void coefficients2(const double* em, const double* e1
 // (odd number of steps) is taken alone -- so that the grid kernels, the point kernels (chunks of CH or CHR steps: both
 // even) and the CPU port produce the same bits.  The four denominators are products of two watched terms each; their
 // product stays far inside the fp64 range (|t| <= ~1e4 in the reference's units, >= 1e-300 only at a flagged point).
+// Not the twisted cylinder: its point kernels form 16 entries per node and lane, four nodes at once do not fit 256 registers.
 #if defined(ES_NO_RCP4)                                // A/B build (timing only: the CPU port pairs the steps)
 template <int FAM> constexpr bool fam_rcp4() { return false; }
 #else
-template <int FAM> constexpr bool fam_rcp4() { return FAM == FAM_CYL0; }
+template <int FAM> constexpr bool fam_rcp4() { return FAM != FAM_CYLT; }
 #endif
 
 template <int FAM, bool TRACK = true>

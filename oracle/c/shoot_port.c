@@ -507,8 +507,9 @@ static int port_eval_core(const port_problem* P, double k, double w, double w_cs
   coefficients(P, e, &s, w, &B0, tp);
   if (P->family <= 1 && P->axis_bc == ES_AXIS_SAUSAGE) { zp = B0.a11; zq = B0.a12; } else { zp = 1.0; zq = 0.0; }
   for (int j = nsteps - 1; j >= 0; --j) {
-    if (P->family == 0 && (j & 1)) {
-      /* fam_rcp4 of the HIP header: step j with step j - 1 for every odd j, one division for both (an even top step alone) */
+    if (P->family != 1 && (j & 1)) {
+      /* fam_rcp4 of the HIP header (every family but the twisted cylinder): step j with step j - 1 for every odd j, one
+         division for both (an even top step alone) */
       double e1[16], em2[16];
       coef Bm2, B2;
       make_entry(P, 2 * j + 1, &s, e);
@@ -516,8 +517,13 @@ static int port_eval_core(const port_problem* P, double k, double w, double w_cs
       make_entry(P, 2 * j - 1, &s, em2);
       make_entry(P, 2 * j - 2, &s, e2);
       coefficients4(P, e, e1, em2, e2, &s, w, &Bm, &B1, &Bm2, &B2, tp);
-      rk4_adjoint_scaled0(&zp, &zq, &B0, &Bm, &B1);
-      rk4_adjoint_scaled0(&zp, &zq, &B1, &Bm2, &B2);
+      if (P->family == 0) {
+        rk4_adjoint_scaled0(&zp, &zq, &B0, &Bm, &B1);
+        rk4_adjoint_scaled0(&zp, &zq, &B1, &Bm2, &B2);
+      } else {
+        rk4_adjoint(diag, &zp, &zq, &B0, &Bm, &B1, h, h2, h6, h3);
+        rk4_adjoint(diag, &zp, &zq, &B1, &Bm2, &B2, h, h2, h6, h3);
+      }
       B0 = B2;
       --j;                                             /* two steps taken: j is now the even step of the pair */
     } else {

@@ -130,8 +130,8 @@ def conditional_block(body):
 
 
 def count(body, rcp_class="rcp_f64", steps_per_rcp=1):
-    """steps_per_rcp: RK4 steps of a point that share one reciprocal (2 for the fp64 marches of the untwisted cylinder,
-    fam_rcp4 in csrc/es_shoot_device.hpp: coefficients4)."""
+    """steps_per_rcp: RK4 steps of a point that share one reciprocal (2 for the fp64 marches of every family but the twisted
+    cylinder, fam_rcp4 in csrc/es_shoot_device.hpp: coefficients4)."""
     c = {}
     cond = conditional_block(body)
     cond_cycles = 0.0
@@ -163,7 +163,7 @@ def table():
         if short.startswith("shoot_grid_kernel"):
             body = march_loop(ks[mangled])
             if body:
-                out[short] = count(body, steps_per_rcp=2 if short.startswith("shoot_grid_kernel<0,") else 1)
+                out[short] = count(body, steps_per_rcp=1 if short.startswith("shoot_grid_kernel<1,") else 2)
         elif short.startswith("shoot_grid_f32_kernel"):
             body = march_loop(ks[mangled], "rcp_f32")
             if body:
