@@ -640,13 +640,13 @@ struct CoefPreF { v2f n11, n12, n21, n22, den; };
 //     iteration).  With S = tau (omega^2 + omega_A^2(boundary)) and delta = S max_j(1 / a_j): all t_j > S if omega is more
 //     than delta outside every interval, all t_j < -S if it is more than delta inside every interval; anything else -- the
 //     continuum points and a margin around the band edges -- goes to fp64, which decides with the per-node tracking of
-//     the fp64 kernels.  Twisted family in addition, per point: the sign bits of C3 D as in the fp64 kernel and the minimum of
+//     the fp64 kernels.  Twisted family in addition, per point: the extremes of C3 over the nodes (the fp64 kernel watches the sign of C3 D; D keeps its sign at a vouched-for point) and the minimum of
 //     |C3| - tau |D (rho t1 + r d/dr[..])| (how close C3 came to zero relative to its leading part).
 template <bool TRACK>
 struct ScreenF {
   v2f mn = {3.0e38f, 3.0e38f};                          // !TRACK: min |t1 t2|
   v2f c3m = {3.0e38f, 3.0e38f};
-  int or3[2] = {0, 0}, and3[2] = {-1, -1};
+  v2f c3lo = {3.0e38f, 3.0e38f}, c3hi = {-3.0e38f, -3.0e38f};   // extremes of C3 over the nodes (twisted family)
 };
 
 // extremes over the nodes of a row of the intervals in which t1 (index 0) and t2 (index 1) are negative; fp32, rounded
@@ -764,9 +764,11 @@ __device__ __forceinline__ void coef_pre_f32(const float* e, v2f w, CoefPreF& C,
     const v2f C3 = c3a + vfma(Q, Q, -(v2(e[13]) * t2T * T));
     // third watched term of the fp64 kernel: the sign of F = r D / C3, i.e. of C3 D.  A point is only vouched for when t1
     // and t2 keep one sign over all nodes (RowBands), and e[3] = rho S > 0: D = e[3] t1 t2 then keeps its sign and C3 D
-    // changes sign exactly where C3 does -- the sign bits of C3 itself are tracked (no product per node).
-    sc.or3[0] |= __float_as_int(C3.x); sc.and3[0] &= __float_as_int(C3.x);
-    sc.or3[1] |= __float_as_int(C3.y); sc.and3[1] &= __float_as_int(C3.y);
+    // changes sign exactly where C3 does -- C3 itself is tracked (no product per node).
+    // (its extremes over the nodes: with the two nodes of a step one v_min3_f32 and one v_max3_f32 per point, where OR-ing
+    // and AND-ing the sign bits took four integer instructions)
+    sc.c3lo.x = fminf(sc.c3lo.x, C3.x); sc.c3hi.x = fmaxf(sc.c3hi.x, C3.x);
+    sc.c3lo.y = fminf(sc.c3lo.y, C3.y); sc.c3hi.y = fmaxf(sc.c3hi.y, C3.y);
     // |C3| - tau |c3a| per component with the source modifiers of the unpacked v_fma_f32 (the packed form has no |x|
     // modifier: four v_and_b32 and a v_pk_fma_f32 per pair and node)
     sc.c3m.x = fminf(sc.c3m.x, fmaf(-F32_TAU_NODE, fabsf(c3a.x), fabsf(C3.x)));
@@ -1023,7 +1025,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
         }
       } else {
         const float c3m = hi_half ? sc.c3m.y : sc.c3m.x;
-        const int or3 = sc.or3[p & 1], and3 = sc.and3[p & 1];
+        const float c3lo = hi_half ? sc.c3lo.y : sc.c3lo.x, c3hi = hi_half ? sc.c3hi.y : sc.c3hi.x;
         // t1, t2: certainly of one sign at every node (judged from the row's interval extremes); or certainly of BOTH signs
         // inside the domain, seen at three sampled nodes (boundary, middle, far end: one of them certainly negative, another
         // certainly positive => ES_PT_CONTINUUM whatever happens in between -- most of a continuum band of a monotone
@@ -1042,7 +1044,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
         if (cross12) {
           crossed = true; node_unsure = false;
         } else if (sure12 && (FAM != FAM_CYLT || c3m >= 0.0f)) {
-          crossed = (FAM == FAM_CYLT) && ((or3 & ~and3) < 0);
+          crossed = (FAM == FAM_CYLT) && (c3lo < 0.0f) && (c3hi >= 0.0f);   // C3 takes both signs (c3m >= 0: never within tau of 0)
           node_unsure = false;
         } else {
           crossed = false; node_unsure = true;
