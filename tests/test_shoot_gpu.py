@@ -600,3 +600,28 @@ def test_grid_timer_counts_launches(es_ctx):
     gp.eval_grid(k, W)
     assert es_ctx.grid_time() == (0.0, 0)
     gp.close()
+
+
+def test_more_tiles_than_one_grid_dimension_holds(es_ctx):
+    """One workgroup per tile: beyond 2^22 tiles the launch uses the y dimension of the grid (es_tile_grid).  4 196 304
+    rows of 64 frequencies (one tile each: 64 lanes x 1 point) of a 12-node cylinder; the rows cycle through 8
+    wavenumbers, so every row -- those past 2^22 in particular -- must carry the bits of the 8-row grid."""
+    import torch
+    from eigensolver_amd import ShootProblem, equilibrium as q
+    gp = ShootProblem(q.CylinderFlow(U_i0=0.6, width=1.0, n_nodes=12), "kink", None, ctx=es_ctx)
+    k8 = np.linspace(0.4, 3.6, 8)
+    W = 2.7 + (np.arange(64) + 0.5) * (2.2 / 64)
+    D8, st8 = gp.eval_grid(k8, W)
+    nk = (1 << 22) + 2000
+    kk = torch.as_tensor(np.tile(k8, nk // 8 + 1)[:nk].copy(), device="cuda")
+    D, st = gp.eval_grid(kk, W)
+    assert D.shape == (nk, 64)
+    D8n, st8n = D8.cpu().numpy(), st8.cpu().numpy()
+    for lo in (0, (1 << 22) - 8, (1 << 22), nk - 2000):      # first rows, the rows around the seam, the tail
+        hi = min(lo + 2000, nk)
+        idx = np.arange(lo, hi) % 8
+        assert np.array_equal(D[lo:hi].cpu().numpy(), D8n[idx], equal_nan=True), lo
+        assert np.array_equal(st[lo:hi].cpu().numpy(), st8n[idx]), lo
+    assert (st8n == 0).sum() > 100
+    del D, st
+    torch.cuda.empty_cache()
