@@ -1172,7 +1172,9 @@ struct GridShape { int pts, wpe; };
 template <int FAM> struct ShapeTable;
 // (three points per lane -- a row of 384 frequencies, configs[2], is 3 x 128 lanes exactly -- was measured too: 1.28 ms per
 // launch against 1.14 ms for 2 x 192: its two-wave workgroups hold 39 KB of LDS each, four fit a CU, two waves per SIMD;
-// wpe[3] = 0 keeps the shape out of the build)
+// wpe[3] = 0 keeps the shape out of the build; measured again at the end of round 3 with a 128-thread instantiation -- 27 KB of
+// LDS, 145 registers, two steps per division --: 1.12 - 1.14 ms against 1.08 - 1.10 ms for 2 x 192, configs[2] 7.18 - 7.25
+// against 7.24 ms per step)
 // (measured again after the kernels became one tile per workgroup -- es_tile_index -- which freed 40 - 90 registers per
 // shape: profiles/r3e_grid_shapes.json, ms per launch, best register cap per point count)
 //   untwisted cylinder 1024 x 4096: 4 pts 5.03 (wpe 3), 2 pts 5.14, 1 pt 5.46; 4096 x 384: 2 pts x 192 lanes 1.27 (wpe 4; 1.32
