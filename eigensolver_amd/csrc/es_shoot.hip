@@ -7,15 +7,16 @@
 //    along the lanes (PTS points per lane, strided by the workgroup size so the 8-byte D stores of a wave are one
 //    contiguous 512 B segment).  k is workgroup uniform, so everything that depends on (node, k, m) but not on omega is
 //    computed ONCE per tile into an LDS table, chunk by chunk (CH RK4 steps per chunk); every lane then reads the same
-//    LDS address (broadcast).  Launch shapes per family: pick_shape().
+//    LDS address (broadcast).  Launch shapes per family: pick_shape(); the launch has exactly one workgroup per tile
+//    (es_tile_grid).  Families with fam_rcp4() take two RK4 steps per division (coefficients4).
 //  * shoot_points_kernel<FAM>: one (k, omega) pair per lane with unrelated k: the k-independent base table is
 //    staged in LDS chunk by chunk (es_shoot_shared.hpp: shoot_point), node entries are formed per lane.
 //  * bracket_flag_kernel: sign change against the omega-neighbour through __shfl_down (lane 63 reads the halo
 //    element), ballot masks + per-block counts; bracket_emit_kernel writes the ordered bracket list.
-//  * refine_kernel<FAM, LANES, CHR>: LANES = 16 lanes per bracket, 17-section rounds steered by a wave ballot (uniform
-//    trip count -> no divergence); refine_polish_kernel: two secant steps with one lane per bracket and the final
-//    classification with the reference's acceptance measure.  The bracket count may stay on the device
-//    (es_shoot_find_roots_async).
+//  * refine_kernel<FAM, LANES, CHR, SECTIONS_ONLY, ONE>: LANES = 16 lanes per bracket, 17-section rounds steered by a wave
+//    ballot (uniform trip count -> no divergence); refine_polish_kernel: two secant steps with one lane per bracket and
+//    the final classification with the reference's acceptance measure.  Both cylinder families launch one round / one step
+//    per launch (ONE); the bracket count may stay on the device (es_shoot_find_roots_async).
 //  * shoot_grid_f32_kernel: fp32 screening march of es_shoot_find_roots_mixed.
 #include <vector>
 #include <cstdio>
