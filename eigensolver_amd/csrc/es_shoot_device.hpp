@@ -194,7 +194,10 @@ __device__ __forceinline__ bool band_crossed(const ShootDev& P, double k, double
 // 1/den_m = den_1 * inv, 1/den_1 = den_m * inv  (one reciprocal per RK4 step instead of two).
 struct CoefPre { double n11, n12, n21, n22, den; };
 
-template <int FAM, bool TRACK = true>
+// C1P: c1_power of the twisted family as a compile-time constant (1 or 2), 0 = read it from the problem at run time.  The
+// one-point kernels branch once per evaluation (shoot_point) and march with the constant: the run-time select between Om and
+// Om^2 is two v_cndmask_b32 per node, four of the 113 instructions of a point-step there; same value either way.
+template <int FAM, bool TRACK = true, int C1P = 0>
 __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, const KScal& s, double w, CoefPre& C,
                                          SignTrack& st) {
   if (FAM == FAM_CYL0) {
@@ -218,7 +221,7 @@ __device__ __forceinline__ void coef_pre(const double* e, const ShootDev& P, con
     const double D = e[3] * t1 * t2;
     const double Q = fma(Om, e[7], fma(Om2, e[6], -(t1 * e[5])));
     const double T = fma(e[9], Om, e[8]);
-    const double OmP = (P.c1_power == 2) ? Om2 : Om;
+    const double OmP = (C1P == 2 || (C1P == 0 && P.c1_power == 2)) ? Om2 : Om;
     const double t2T = t2 * T;
     const double C1 = fma(Q, OmP, -(e[10] * t2T));
     const double C2 = fma(Om2, Om2, -(e[11] * t2));
@@ -278,11 +281,11 @@ __device__ __forceinline__ void coef_finish(const CoefPre& C, double inv, Coef& 
 }
 
 // single node (first node of a traversal): its own division
-template <int FAM, bool TRACK = true>
+template <int FAM, bool TRACK = true, int C1P = 0>
 __device__ __forceinline__ void coefficients(const double* e, const ShootDev& P, const KScal& s, double w,
                                              Coef& A, SignTrack& st) {
   CoefPre C;
-  coef_pre<FAM, TRACK>(e, P, s, w, C, st);
+  coef_pre<FAM, TRACK, C1P>(e, P, s, w, C, st);
   coef_finish<FAM>(C, 1.0 / C.den, A);
 }
 
@@ -305,12 +308,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 
 // two nodes of one RK4 step (mid-point, end-point) with one division
-template <int FAM, bool TRACK = true>
+template <int FAM, bool TRACK = true, int C1P = 0>
 __device__ __forceinline__ void coefficients2(const double* em, const double* e1, const ShootDev& P,
                                               const KScal& s, double w, Coef& Am, Coef& A1, SignTrack& st) {
   CoefPre Cm, C1;
-  coef_pre<FAM, TRACK>(em, P, s, w, Cm, st);
-  coef_pre<FAM, TRACK>(e1, P, s, w, C1, st);
+  coef_pre<FAM, TRACK, C1P>(em, P, s, w, Cm, st);
+  coef_pre<FAM, TRACK, C1P>(e1, P, s, w, C1, st);
   const double inv = fast_rcp(Cm.den * C1.den);
   coef_finish<FAM>(Cm, C1.den * inv, Am);
   coef_finish<FAM>(C1, Cm.den * inv, A1);

@@ -62,7 +62,7 @@ __device__ __forceinline__ void finish_point(const ShootDev& P, const Mismatch& 
 // LDS address per node (broadcast) and forms its own node entries.  Same arithmetic, in the same order, as the grid
 // kernel.  (Reading the table with wave-uniform scalar loads instead left these latency-bound kernels -- one wave
 // per SIMD or fewer -- waiting ~400 ns per RK4 step.)
-template <int FAM, bool TRACK, bool BANDS = !TRACK>
+template <int FAM, bool TRACK, bool BANDS = !TRACK, int C1P = 0>
 __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, double w, double w_cst, double& D,
                                                  double& rel, uint8_t& st, double* __restrict__ sb) {
   constexpr int NE = FamTraits<FAM>::NE;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
 #pragma unroll
       for (int f = 0; f < NB; ++f) b[f] = sb[2 * nst * NB + f];
       make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
-      coefficients<FAM, TRACK>(e, P, s, w, B0, trk);
+      coefficients<FAM, TRACK, C1P>(e, P, s, w, B0, trk);
       adjoint_start(P, B0, zp, zq);
     }
     // The coefficients of a step (of a pair of steps: fam_rcp4) are formed one iteration AHEAD of the RK4 stages that use
@@ -107,7 +107,7 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
         Coef Bm, B1;
         ES_ENTRY(2 * j + 1, e)
         ES_ENTRY(2 * j, e2)
-        coefficients2<FAM, TRACK>(e, e2, P, s, w, Bm, B1, trk);
+        coefficients2<FAM, TRACK, C1P>(e, e2, P, s, w, Bm, B1, trk);
         adjoint_step<FAM>(zp, zq, B0, Bm, B1, h, h2, h6, h3);
         B0 = B1;
         --j;
@@ -140,12 +140,12 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
       Coef Cm, C1;
       ES_ENTRY(2 * j + 1, e)
       ES_ENTRY(2 * j, e2)
-      coefficients2<FAM, TRACK>(e, e2, P, s, w, Cm, C1, trk);
+      coefficients2<FAM, TRACK, C1P>(e, e2, P, s, w, Cm, C1, trk);
       for (; j >= 1; --j) {
         Coef Nm, N1;
         ES_ENTRY(2 * j - 1, e)
         ES_ENTRY(2 * j - 2, e2)
-        coefficients2<FAM, TRACK>(e, e2, P, s, w, Nm, N1, trk);
+        coefficients2<FAM, TRACK, C1P>(e, e2, P, s, w, Nm, N1, trk);
         adjoint_step<FAM>(zp, zq, B0, Cm, C1, h, h2, h6, h3);
         B0 = C1;
         Cm = Nm; C1 = N1;
@@ -276,7 +276,15 @@ __device__ __forceinline__ void shoot_point_wavegroup(const ShootDev& P, double 
 template <int FAM, bool STATUS = true>
 __device__ __forceinline__ void shoot_point(const ShootDev& P, double k, double w, double w_cst, double& D,
                                             double& rel, uint8_t& st, double* __restrict__ sb) {
-  if (!STATUS) {
+  if (FAM == FAM_CYLT) {                               // uniform branches: c1_power as a constant of the march (coef_pre)
+    if (!STATUS) {
+      if (P.c1_power == 2) shoot_point_impl<FAM, false, false, 2>(P, k, w, w_cst, D, rel, st, sb);
+      else shoot_point_impl<FAM, false, false, 1>(P, k, w, w_cst, D, rel, st, sb);
+    } else {
+      if (P.c1_power == 2) shoot_point_impl<FAM, true, false, 2>(P, k, w, w_cst, D, rel, st, sb);
+      else shoot_point_impl<FAM, true, false, 1>(P, k, w, w_cst, D, rel, st, sb);
+    }
+  } else if (!STATUS) {
     shoot_point_impl<FAM, false, false>(P, k, w, w_cst, D, rel, st, sb);
   } else if (fam_has_bands<FAM>() && P.use_bands) shoot_point_impl<FAM, !fam_has_bands<FAM>()>(P, k, w, w_cst, D, rel, st, sb);   // uniform branch
   else shoot_point_impl<FAM, true>(P, k, w, w_cst, D, rel, st, sb);
