@@ -56,241 +56,32 @@ inline dim3 es_tile_grid(long tiles) {
   return tiles <= ES_TILE_GRID_X ? dim3((unsigned)tiles) : dim3((unsigned)ES_TILE_GRID_X, (unsigned)((tiles + ES_TILE_GRID_X - 1) / ES_TILE_GRID_X));
 }
 
+// ROWS = 2: a workgroup holds TWO k-rows, waves 0, 1 the first and waves 2, 3 the second (128 lanes x PTS points each; its
+// own LDS table per row).  A workgroup should have four waves, one per SIMD of its CU: the waves of a workgroup are tied to
+// each other by the barriers around every LDS chunk, so a CU filled with three-wave workgroups runs at the pace of the SIMD
+// that got four waves while another got two -- measured on 4096 rows, N = 2001, ns per point-step relative to rows of 1024
+// frequencies (4 points x 256 lanes): 768 (4 x 192 lanes) 1.17, 384 (2 x 192) 1.17, 512 (4 x 128) 1.39, 256 (4 x 64) 1.83
+// (tools/probe/time_row_width.py).  Rows of at most 128 x PTS frequencies therefore go two to a workgroup.
 template <int FAM, int PTS, int MAXT, bool TRACK, int WPE = 0>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 1, WPE ? WPE : 8)))
 void shoot_grid_kernel(ShootDev P, const double* __restrict__ kv, int nk,
                                                           const double* __restrict__ wv, int nw, int w_mode,
                                                           double* __restrict__ Dout, double* __restrict__ relout,
                                                           uint8_t* __restrict__ stout, GridOpts opts) {
-  constexpr int NE = FamTraits<FAM>::NE;
-  // even row stride and a 16-byte aligned table: the entries of nodes 2j, 2j+1 of every row are one aligned 16-byte pair,
-  // read by ds_read_b128 at an immediate offset from ONE address register (with the odd stride every other row needed
-  // ds_read2_b64 from its own base register: 7 address moves per loop iteration, 2 % of its VALU instructions)
-  constexpr int LSTRIDE = 2 * CH + 2;
-  // two RK4 steps per loop iteration where the registers allow it (two coefficients per point, 4 points per lane)
-  constexpr bool PAIR = (FAM == FAM_CYL0) && !TRACK;
-  // register-capped instantiations (WPE != 0) park the exterior results in LDS during the march instead of letting
-  // the compiler spill them to scratch (HBM): 4 doubles per point, lane-contiguous (conflict-free)
-  constexpr bool STASH = (WPE != 0);
-  __shared__ double xstash[STASH ? 4 * PTS * MAXT : 1];
-  __shared__ __attribute__((aligned(16))) double lds[NE * LSTRIDE];
-  const int T = blockDim.x;
-  const int nsteps = P.n_nodes - 1;
-  const double h = P.h, h2 = 0.5 * P.h, h6 = P.h / 6.0, h3 = P.h / 3.0;
+  constexpr int ROWS = 1;
+#include "es_shoot_grid_body.hpp"
+}
 
-  // tile = (k-row, omega-segment of T*PTS points): rows wider than one segment are split across workgroups, so the
-  // number of workgroups is nk * nseg (narrow k-tiles of a multi-GPU run still fill the chip, and the tail of the
-  // launch is one segment long instead of one row)
-  const int span = T * PTS;
-  const int ncols = opts.cols ? opts.cols[0] : nw;     // columns to evaluate (workgroup-uniform)
-  const int col_base = (opts.part == 2) ? (ncols / opts.main_span) * opts.main_span : 0;
-  const int nseg = (opts.part == 2) ? opts.main_span / span : (nw + span - 1) / span;
-  const long ntiles = (long)nk * nseg;
-  for (long tile = es_tile_index(), once = 1; once && tile < ntiles; once = 0) {
-    // segment-major order: consecutive workgroup ids (dealt round-robin to the 8 XCDs) are consecutive k-rows of one
-    // omega-segment.  With the row-major order tile = row * nseg + segment and nseg = 4, segment s of every row went to
-    // XCDs s and s + 4: segments whose points are dead (continuum, leaky) or absent (compacted launch) idled two XCDs
-    // while the other six carried the launch
-    const int seg = (int)(tile / nk);
-    const int row = (int)(tile - (long)seg * nk);
-    const int w0 = col_base + seg * span;
-    if (w0 >= ncols) continue;                         // segment beyond the live columns
-    if (opts.part == 1 && w0 + span > ncols) continue; // partly filled segment: left to the remainder launch
-    const double k = kv[row];
-    const KScal s = make_kscal(P, k);
-    {
-      double w[PTS], zp[PTS], zq[PTS];
-      Coef B0[PTS], B1[PTS];
-      SignTrack trk[PTS];
-      bool inr[PTS];
-      int iwp[PTS];
-      // exterior closed form first: here nothing of the march is live, so the ~100 VGPRs of the Bessel code overlap with
-      // nothing and only its results are carried through the march (no call frame).
-      // a wave none of whose points has an evanescent exterior (leaky / non-finite: D is NaN whatever the march gives)
-      // only takes part in the LDS staging and the barriers
-      ExteriorLite X[PTS];
-      bool lane_live = false;
-      if (STASH) {
-        // ONE copy of the exterior code, executed PTS times (not unrolled): the results go to LDS at once, the frequency
-        // is formed again for the march below (same operations, same value) -- so the register cap of the shape costs no
-        // spill in the Bessel code and the kernel carries one copy of it instead of PTS
-#pragma unroll 1
-        for (int p = 0; p < PTS; ++p) {
-          const int ic = w0 + p * T + (int)threadIdx.x;
-          const bool in = ic < ncols;
-          const int iw = in ? (opts.cols ? opts.cols[1 + ic] : ic) : 0;
-          const double wp = in ? pick_w(wv, w_mode, k, row, nw, iw) : 1.0;
-          const ExteriorLite Xp = exterior_lite(P, k, wp, wp);
-          // with ES_EVAL_SKIP_CONTINUUM a point inside a continuum band (known before the march) is not worth a march
-          const bool dead = opts.skip && !TRACK && band_crossed(P, k, wp);
-          lane_live = lane_live || (in && Xp.status == ES_PT_OK && !dead);
-          double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;   // lane-contiguous: conflict-free
-          xs[0] = Xp.outer; xs[MAXT] = Xp.yb; xs[2 * MAXT] = Xp.Oe; xs[3 * MAXT] = (double)Xp.status;
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) {
-        const int ic = w0 + p * T + (int)threadIdx.x;
-        inr[p] = ic < ncols;
-        iwp[p] = inr[p] ? (opts.cols ? opts.cols[1 + ic] : ic) : 0;
-        w[p] = inr[p] ? pick_w(wv, w_mode, k, row, nw, iwp[p]) : 1.0;
-      }
-      if (!STASH) {
-#pragma unroll
-        for (int p = 0; p < PTS; ++p) {
-          X[p] = exterior_lite(P, k, w[p], w[p]);
-          const bool dead = opts.skip && !TRACK && band_crossed(P, k, w[p]);
-          lane_live = lane_live || (inr[p] && X[p].status == ES_PT_OK && !dead);
-        }
-      }
-      const bool wave_live = __any(lane_live);
-      // a workgroup without any evanescent point (a whole omega-segment of leaky / singular points) skips the march
-      const bool wg_live = __syncthreads_or(wave_live ? 1 : 0) != 0;
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) { zp[p] = 0.0; zq[p] = 0.0; }
-      // adjoint march: chunks from the far end of the interior back to the boundary
-      const int nchunks = wg_live ? (nsteps + CH - 1) / CH : 0;
-      for (int c = nchunks - 1; c >= 0; --c) {
-        const int c0 = c * CH;
-        const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
-        __syncthreads();                               // previous chunk fully consumed
-        for (int i = threadIdx.x; i < 2 * nst + 1; i += T) {
-          double b[FamTraits<FAM>::NB], e[NE];
-          load_base<FAM>(P, 2 * c0 + i, b);
-          make_entry<FAM, fam_scaled<FAM>()>(b, s, e);
-#pragma unroll
-          for (int f = 0; f < NE; ++f) lds[f * LSTRIDE + i] = e[f];
-        }
-        __syncthreads();
-        if (!wave_live) continue;
-        if (c == nchunks - 1) {                        // last node: start vector of the march
-          double eL[NE];
-#pragma unroll
-          for (int f = 0; f < NE; ++f) eL[f] = lds[f * LSTRIDE + 2 * nst];
-#pragma unroll
-          for (int p = 0; p < PTS; ++p) {
-            coefficients<FAM, TRACK>(eL, P, s, w[p], B0[p], trk[p]);
-            adjoint_start(P, B0[p], zp[p], zq[p]);
-          }
-        }
-        // one RK4 step of all PTS points: coefficients of node 2j+1 / 2j from LDS (broadcast reads), start
-        // coefficients BIN, end coefficients written to BOUT (the next step's start)
-#define ES_MARCH_STEP(J, BIN, BOUT)                                                         \
-        {                                                                                   \
-          double em[NE], e1[NE];                                                            \
-          _Pragma("unroll") for (int f = 0; f < NE; ++f) {                                  \
-            em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                         \
-            e1[f] = lds[f * LSTRIDE + 2 * (J)];                                             \
-          }                                                                                 \
-          _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                 \
-            Coef Bm;                                                                        \
-            coefficients2<FAM, TRACK>(em, e1, P, s, w[p], Bm, BOUT[p], trk[p]);             \
-            adjoint_step<FAM>(zp[p], zq[p], BIN[p], Bm, BOUT[p], h, h2, h6, h3);                             \
-          }                                                                                 \
-        }
-        // two RK4 steps of all PTS points with ONE division per point (coefficients4: families with fam_rcp4()): nodes
-        // 2J+1, 2J (step J) and 2J-1, 2J-2 (step J-1); start coefficients BIN, end coefficients of step J-1 to BOUT
-#define ES_MARCH_PAIR(J, BIN, BOUT)                                                         \
-        {                                                                                   \
-          double em[NE], e1[NE], em2[NE], e12[NE];                                          \
-          _Pragma("unroll") for (int f = 0; f < NE; ++f) {                                  \
-            em[f] = lds[f * LSTRIDE + 2 * (J) + 1];                                         \
-            e1[f] = lds[f * LSTRIDE + 2 * (J)];                                             \
-            em2[f] = lds[f * LSTRIDE + 2 * (J) - 1];                                        \
-            e12[f] = lds[f * LSTRIDE + 2 * (J) - 2];                                        \
-          }                                                                                 \
-          _Pragma("unroll") for (int p = 0; p < PTS; ++p) {                                 \
-            Coef Bm, Bj, Bm2;                                                               \
-            coefficients4<FAM, TRACK>(em, e1, em2, e12, P, s, w[p], Bm, Bj, Bm2, BOUT[p], trk[p]); \
-            adjoint_step<FAM>(zp[p], zq[p], BIN[p], Bm, Bj, h, h2, h6, h3);                 \
-            adjoint_step<FAM>(zp[p], zq[p], Bj, Bm2, BOUT[p], h, h2, h6, h3);               \
-          }                                                                                 \
-        }
-        int j = nst - 1;
-        if (fam_rcp4<FAM>()) {
-          // step j with step j - 1 for every odd j (the pairing every fp64 march of the family uses: coefficients4); an
-          // even top step alone; the pairs two per iteration with the roles of B0 / B1 swapped (no coefficient copies)
-          if (nst & 1) {
-            ES_MARCH_STEP(j, B0, B1)
-#pragma unroll
-            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
-            --j;
-          }
-          if (TRACK && FAM != FAM_CYL0) {
-            // the sign-tracking fall-backs of the slab families (profiles whose continuum intervals do not overlap) keep
-            // three or four watched terms per point: one pair per iteration (two would not fit 256 registers)
-            for (; j >= 1; j -= 2) {
-              ES_MARCH_PAIR(j, B0, B1)
-#pragma unroll
-              for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
-            }
-          } else {
-            if (((j + 1) >> 1) & 1) {                  // odd number of pairs: one ahead of the loop
-              ES_MARCH_PAIR(j, B0, B1)
-#pragma unroll
-              for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
-              j -= 2;
-            }
-            for (; j >= 3; j -= 4) {
-              ES_MARCH_PAIR(j, B0, B1)
-              ES_MARCH_PAIR(j - 2, B1, B0)
-            }
-          }
-        } else if (PAIR) {
-          // steps in pairs with the roles of B0 / B1 swapped, so that no coefficient is copied between iterations
-          if (nst & 1) {
-            ES_MARCH_STEP(j, B0, B1)
-#pragma unroll
-            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
-            --j;
-          }
-          for (; j >= 1; j -= 2) {
-            ES_MARCH_STEP(j, B0, B1)
-            ES_MARCH_STEP(j - 1, B1, B0)
-          }
-        } else {
-          for (; j >= 0; --j) {
-            ES_MARCH_STEP(j, B0, B1)
-#pragma unroll
-            for (int p = 0; p < PTS; ++p) B0[p] = B1[p];
-          }
-        }
-#undef ES_MARCH_PAIR
-#undef ES_MARCH_STEP
-#pragma unroll
-        for (int p = 0; p < PTS; ++p) adjoint_rescale<FAM>(zp[p], zq[p], nsteps - c0 - nst, nsteps - c0);
-      }
-      if (STASH) {
-#pragma unroll
-        for (int p = 0; p < PTS; ++p) {
-          const double* xs = xstash + (size_t)(4 * p) * MAXT + threadIdx.x;
-          X[p].outer = xs[0]; X[p].yb = xs[MAXT]; X[p].Oe = xs[2 * MAXT]; X[p].status = (int)xs[3 * MAXT];
-        }
-      }
-      // boundary: exterior closed form + far-end condition + mismatch
-      double bf[FamTraits<FAM>::NB], ef[NE];
-      load_base<FAM>(P, 0, bf);
-      make_entry<FAM>(bf, s, ef);
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) {
-        if (!inr[p]) continue;
-        const int iw = iwp[p];
-        const Mismatch M = boundary_algebra<FAM>(P, s, w[p], X[p], zp[p], zq[p], ef);
-        double D, rel; uint8_t st;
-        const bool crossed = TRACK ? trk[p].crossed() : band_crossed(P, k, w[p]);
-        finish_point(P, M, X[p], crossed, D, rel, st);
-        // a band point of ES_EVAL_SKIP_CONTINUUM may not have been marched at all (a wave or workgroup of dead points keeps
-        // z = 0, the boundary algebra gives 0/0 and finish_point says NONFINITE): its status is CONTINUUM, as the header
-        // documents (the fp32 screening kernel does the same)
-        if (opts.skip && !TRACK && crossed && X[p].status == ES_PT_OK) st = ES_PT_CONTINUUM;
-        if (opts.skip && st == ES_PT_CONTINUUM) { D = NAN; rel = NAN; }
-        const size_t o = (size_t)row * nw + iw;
-        Dout[o] = D;
-        stout[o] = st;
-        if (relout) relout[o] = rel;
-      }
-    }
-  }
+// two k-rows per workgroup (ROWS = 2): 256 threads, never compacted launches
+template <int FAM, int PTS, bool TRACK, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void shoot_grid_kernel_r2(ShootDev P, const double* __restrict__ kv, int nk,
+                                                          const double* __restrict__ wv, int nw, int w_mode,
+                                                          double* __restrict__ Dout, double* __restrict__ relout,
+                                                          uint8_t* __restrict__ stout, GridOpts opts) {
+  constexpr int ROWS = 2;
+  constexpr int MAXT = 256;
+#include "es_shoot_grid_body.hpp"
 }
 
 // ---- ES_EVAL_SKIP_CONTINUUM with ES_W_PHASE_SPEED: whole omega-columns inside a continuum band ----------------------
@@ -1171,16 +962,17 @@ struct GridShape { int pts, wpe; };
 // exactly, 4 points x 128 lanes waste a quarter) and about not spilling; four points per lane share the LDS reads and
 // the loop overhead best.  WPE = 4 is used where the kernel fits 128 registers without a spill.
 template <int FAM> struct ShapeTable;
-// (three points per lane -- a row of 384 frequencies, configs[2], is 3 x 128 lanes exactly -- was measured too: 1.28 ms per
+// (untwisted cylinder: three points per lane are built for rows of 513 - 768 frequencies = 3 x 256 lanes, a four-wave workgroup
+// where 4 x 192 lanes make a three-wave one.  For a row of 384 frequencies, configs[2], 3 x 128 lanes was measured too: 1.28 ms per
 // launch against 1.14 ms for 2 x 192: its two-wave workgroups hold 39 KB of LDS each, four fit a CU, two waves per SIMD;
-// wpe[3] = 0 keeps the shape out of the build; measured again at the end of round 3 with a 128-thread instantiation -- 27 KB of
-// LDS, 145 registers, two steps per division --: 1.12 - 1.14 ms against 1.08 - 1.10 ms for 2 x 192, configs[2] 7.18 - 7.25
-// against 7.24 ms per step)
+// measured again at the end of round 3 with a 128-thread instantiation -- 27 KB of LDS, 145 registers, two steps per division --:
+// 1.12 - 1.14 ms against 1.08 - 1.10 ms for 2 x 192, configs[2] 7.18 - 7.25 against 7.24 ms per step; what rows of 384 needed was a
+// four-wave workgroup: two rows each, shoot_grid_kernel_r2, 0.99 ms.  The other families keep wpe[3] = 0.)
 // (measured again after the kernels became one tile per workgroup -- es_tile_index -- which freed 40 - 90 registers per
 // shape: profiles/r3e_grid_shapes.json, ms per launch, best register cap per point count)
 //   untwisted cylinder 1024 x 4096: 4 pts 5.03 (wpe 3), 2 pts 5.14, 1 pt 5.46; 4096 x 384: 2 pts x 192 lanes 1.27 (wpe 4; 1.32
 //   at wpe 3), 4 pts x 128 lanes 1.80
-template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 3, 0, 3}; static constexpr double cost[5] = {0, 1.09, 1.025, 0, 1.0}; };
+template <> struct ShapeTable<FAM_CYL0>  { static constexpr int wpe[5] = {0, 4, 3, 3, 3}; static constexpr double cost[5] = {0, 1.09, 1.025, 1.01, 1.0}; };
 // twisted cylinder 1024 x 1024, N = 2000: 4 pts 6.60 (200 registers, two workgroups per CU), 2 pts 6.70, 1 pt 6.85 (7.8 - 8.2
 // for every shape while the tile loop was there)
 template <> struct ShapeTable<FAM_CYLT>  { static constexpr int wpe[5] = {0, 3, 2, 0, 2}; static constexpr double cost[5] = {0, 1.04, 1.015, 0, 1.0}; };
@@ -1205,7 +997,10 @@ GridShape pick_shape(int nw, bool track) {
     const int T = shape_threads(nw, pts);
     const long span = (long)T * pts;
     const long padded = (nw + span - 1) / span * span;
-    const double c = (double)padded * ShapeTable<FAM>::cost[pts];
+    // workgroups of fewer than four waves do not load the four SIMDs of a CU evenly and their waves wait for each other at
+    // the chunk barriers: ns per point-step against four-wave workgroups, measured (tools/probe/time_row_width.py)
+    static const double wave_count_cost[5] = {0.0, 1.83, 1.39, 1.17, 1.0};
+    const double c = (double)padded * ShapeTable<FAM>::cost[pts] * wave_count_cost[T / 64];
     if (c < best_cost) { best_cost = c; best = GridShape{pts, ShapeTable<FAM>::wpe[pts]}; }
   }
   // per-node sign tracking of a band family (profiles whose continuum intervals do not overlap): 6 - 12 more registers
@@ -1230,6 +1025,16 @@ constexpr bool shape_built() {
   if (FAM == FAM_CYL0 && PTS == 4 && WPE == 2) return true;   // A/B aid for the headline shape (ES_GRID_SHAPE=4,2: 175 VGPRs, no spill)
   return ShapeTable<FAM>::wpe[PTS] == WPE;
 #endif
+}
+
+// rows of at most 512 frequencies of the untwisted cylinder go two to a four-wave workgroup (shoot_grid_kernel_r2: 128 lanes x
+// ceil(nw / 128) points per row) unless the problem needs per-node sign tracking; ES_GRID_ROWS2=0 and ES_GRID_SHAPE select
+// the one-row shapes (A/B aids)
+template <int FAM>
+bool rows2_shape(int nw, bool track) {
+  if (FAM != FAM_CYL0 || track || nw > 512) return false;
+  const char* r2 = getenv("ES_GRID_ROWS2");
+  return !(r2 && r2[0] == '0') && !getenv("ES_GRID_SHAPE");
 }
 
 template <int FAM>
@@ -1270,6 +1075,18 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   const dim3 grid = es_tile_grid(tiles);
   bool launched = false;
   es_timer_begin(ctx);
+  if constexpr (FAM == FAM_CYL0) {
+    if (rows2_shape<FAM>(nw, track) && !opts.cols && nk >= 2) {
+      const int pts2 = (nw + 127) / 128;
+      const dim3 grid2 = es_tile_grid(((long)nk + 1) / 2);
+#define ES_R2(P_)                                                                                                   \
+      if (pts2 == P_) hipLaunchKernelGGL((shoot_grid_kernel_r2<FAM, P_, false, 3>), grid2, dim3(256), 0, ctx->stream, \
+                                         prob->dev, d_k, nk, d_w, nw, w_mode, d_D, d_rel, d_status, opts);
+      ES_R2(1) ES_R2(2) ES_R2(3) ES_R2(4)
+#undef ES_R2
+      launched = true;
+    }
+  }
   auto one = [&](auto pts_c, auto wpe_c, auto track_c) {
     constexpr int PTS = decltype(pts_c)::value, WPE = decltype(wpe_c)::value;
     constexpr bool TRACK = decltype(track_c)::value;
@@ -1636,6 +1453,7 @@ extern "C" int es_shoot_grid_shape(es_context* ctx, const es_problem* prob, int 
     default: return ES_ERR_UNSUPPORTED;
   }
   *h_pts = g.pts; *h_wpe = g.wpe; *h_track = track ? 1 : 0;
+  if (prob->dev.family == FAM_CYL0 && rows2_shape<FAM_CYL0>(nw, track)) { *h_pts = -((nw + 127) / 128); *h_wpe = 3; }
   return ES_SUCCESS;
 }
 

@@ -110,6 +110,8 @@ class ShootProblem:
         pts, wpe, trk = C.c_int(0), C.c_int(0), C.c_int(0)
         _lib.check(self.ctx.handle, self.ctx.lib.es_shoot_grid_shape(self.ctx.handle, self.handle, int(nw), C.byref(pts),
                                                                      C.byref(wpe), C.byref(trk)))
+        if pts.value < 0:                                   # two k-rows per workgroup (es_shoot_grid_shape)
+            return f"shoot_grid_kernel_r2<{int(self.desc.geometry)},{-pts.value},{'true' if trk.value else 'false'},{wpe.value}>"
         return f"shoot_grid_kernel<{int(self.desc.geometry)},{pts.value},256,{'true' if trk.value else 'false'},{wpe.value}>"
 
     def eval_points(self, k, w, want_rel=False):

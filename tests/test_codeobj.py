@@ -30,7 +30,7 @@ def test_no_spill_inside_a_march_loop(built):
     for name, v in loops.items():
         if name.startswith("shoot_grid_kernel"):
             assert v["scratch_in_loop"] == 0, (name, v["scratch_in_loop"])
-            assert v["point_steps_per_iteration"] in (1, 2, 4, 8, 16), (name, v["point_steps_per_iteration"])
+            assert v["point_steps_per_iteration"] in (1, 2, 3, 4, 6, 8, 12, 16), (name, v["point_steps_per_iteration"])
     # whole-kernel spill counts of the fp64 grid shapes: none since the kernels process one tile per workgroup (the tile
     # loop of rounds 2 - 3 carried hoisted tile-invariant values through the march: 168 registers + 6 spilled values for
     # the headline shape, 123 and none without it)

@@ -491,13 +491,15 @@ def test_grid_shapes_bit_identical(es_ctx, name, monkeypatch):
     k, W = cases.sample_kw(case, nk=3, nw=1111, seed=5)
     pts, wpe, trk = C.c_int(0), C.c_int(0), C.c_int(0)
     ref = None
+    monkeypatch.setenv("ES_GRID_ROWS2", "0")                # the one-row shapes (two rows per workgroup: its own test below)
     for nw in (1111, 130):
         wpes = {}
         monkeypatch.delenv("ES_GRID_SHAPE", raising=False)
         # the register cap the table pairs with each points-per-lane count: ask the library with row widths that select it
         for probe_nw in (64, 128, 192, 256, 384, 512, 1024, 4096):
             _lib.check(es_ctx.handle, es_ctx.lib.es_shoot_grid_shape(es_ctx.handle, gp.handle, probe_nw, C.byref(pts), C.byref(wpe), C.byref(trk)))
-            wpes[pts.value] = wpe.value
+            if pts.value > 0:                            # negative: the two-rows-per-workgroup shape (its own test below)
+                wpes[pts.value] = wpe.value
         assert len(wpes) >= 2, wpes
         out = []
         for p_, w_ in sorted(wpes.items()):
@@ -625,3 +627,31 @@ def test_more_tiles_than_one_grid_dimension_holds(es_ctx):
     assert (st8n == 0).sum() > 100
     del D, st
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("nk,nw", [(7, 384), (2, 100), (5, 512), (64, 129), (3, 257)])
+def test_two_rows_per_workgroup_bit_identical(es_ctx, monkeypatch, nk, nw):
+    """Rows of at most 512 frequencies of the untwisted cylinder are marched two to a workgroup (shoot_grid_kernel_r2); same
+    bits as the one-row shapes (ES_GRID_ROWS2=0), odd row counts and ragged widths included, per-row frequencies too."""
+    import ctypes as C
+    from eigensolver_amd import _lib
+    case = CASES["CF_flow_kink"]
+    gp = _gpu_problem(es_ctx, case)
+    k, W = cases.sample_kw(case, nk=nk, nw=nw, seed=11)
+    pts, wpe, trk = C.c_int(0), C.c_int(0), C.c_int(0)
+    monkeypatch.delenv("ES_GRID_ROWS2", raising=False)
+    monkeypatch.delenv("ES_GRID_SHAPE", raising=False)
+    _lib.check(es_ctx.handle, es_ctx.lib.es_shoot_grid_shape(es_ctx.handle, gp.handle, nw, C.byref(pts), C.byref(wpe), C.byref(trk)))
+    assert pts.value == -((nw + 127) // 128), pts.value
+    D2, st2, rel2 = gp.eval_grid(k, W, want_rel=True)
+    Wrow = (k[:, None] * W[None, :]).copy()
+    Dr2, sr2 = gp.eval_grid(k, Wrow, w_mode=2)[:2]
+    monkeypatch.setenv("ES_GRID_ROWS2", "0")
+    _lib.check(es_ctx.handle, es_ctx.lib.es_shoot_grid_shape(es_ctx.handle, gp.handle, nw, C.byref(pts), C.byref(wpe), C.byref(trk)))
+    assert pts.value > 0
+    D1, st1, rel1 = gp.eval_grid(k, W, want_rel=True)
+    Dr1, sr1 = gp.eval_grid(k, Wrow, w_mode=2)[:2]
+    assert np.array_equal(D2.cpu().numpy(), D1.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(st2.cpu().numpy(), st1.cpu().numpy()) and np.array_equal(rel2.cpu().numpy(), rel1.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(Dr2.cpu().numpy(), Dr1.cpu().numpy(), equal_nan=True) and np.array_equal(sr2.cpu().numpy(), sr1.cpu().numpy())
+    assert (st1.cpu().numpy() == 0).sum() > nk * nw // 4
