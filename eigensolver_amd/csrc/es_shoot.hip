@@ -739,7 +739,7 @@ void shoot_grid_f32_kernel(ShootDev P, const double* __restrict__ kv, int nk, co
       const int c0 = c * CH;
       const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
       __syncthreads();
-      for (int i = threadIdx.x; i < 2 * nst + 1; i += T) {
+      for (int i = threadIdx.x; i < 2 * nst + ES_FAR_NODE(c, nchunks); i += T) {   // far node: first chunk only (es_shoot_grid_body.hpp)
         double b[FamTraits<FAM>::NB], e[NE];
         load_base<FAM>(P, 2 * c0 + i, b);
         make_entry<FAM>(b, s, e);                      // fp64, rounded to fp32 once

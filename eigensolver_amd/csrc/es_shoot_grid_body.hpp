@@ -101,10 +101,14 @@
         const int c0 = c * CH;
         const int nst = (nsteps - c0 < CH) ? (nsteps - c0) : CH;
         __syncthreads();                               // previous chunk fully consumed
-        for (int i = threadIdx.x; i < ROWS * (2 * nst + 1); i += TW) {
+        // the entry of the chunk's far node (index 2 nst) is only read by the chunk that starts the march (its coefficients
+        // come over in B0 from the chunk before otherwise): 2 nst entries = ONE pass of 256 threads for a full chunk, where
+        // 2 nst + 1 took a second pass for a single entry
+        const int nstage = 2 * nst + ES_FAR_NODE(c, nchunks);
+        for (int i = threadIdx.x; i < ROWS * nstage; i += TW) {
           double b[FamTraits<FAM>::NB], e[NE];
-          const int r = (ROWS == 2 && i >= 2 * nst + 1) ? 1 : 0;           // table of the workgroup's first / second row
-          const int node = i - r * (2 * nst + 1);
+          const int r = (ROWS == 2 && i >= nstage) ? 1 : 0;                // table of the workgroup's first / second row
+          const int node = i - r * nstage;
           load_base<FAM>(P, 2 * c0 + node, b);
           if (ROWS == 1) {
             make_entry<FAM, fam_scaled<FAM>()>(b, s, e);

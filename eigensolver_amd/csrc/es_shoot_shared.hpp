@@ -12,6 +12,14 @@ struct es_problem {
 namespace es_shoot_shared {
 
 constexpr int ES_REFINE_POLISH = 2;   // regula-falsi steps after the 9-section rounds (0: report the bracket midpoint)
+// 1 if chunk c_ of n_ stages the entry of its far node (index 2 nst): only the chunk that starts the march reads it -- the others
+// get its coefficients in B0 from the chunk before -- and 2 nst entries are ONE pass of 256 threads (four of a 64-lane wave
+// building 4 x 64) where 2 nst + 1 took one more pass for a single entry.  -DES_STAGE_FAR_NODE_ALWAYS: A/B build.
+#if defined(ES_STAGE_FAR_NODE_ALWAYS)
+#define ES_FAR_NODE(c_, n_) 1
+#else
+#define ES_FAR_NODE(c_, n_) (((c_) == (n_) - 1) ? 1 : 0)
+#endif
 constexpr int CH = 128;   // RK4 steps per LDS chunk: (2*CH+1) * NE * 8 B of LDS (14.4 KiB for NE = 7)
 
 template <int FAM>
@@ -83,7 +91,8 @@ __device__ __forceinline__ void shoot_point_impl(const ShootDev& P, double k, do
     __syncthreads();                                   // previous chunk fully consumed
 #pragma unroll
     for (int f = 0; f < NB; ++f)
-      for (int i = threadIdx.x; i < 2 * nst + 1; i += blockDim.x) sb[i * NB + f] = P.base[(size_t)f * P.npts + 2 * c0 + i];
+      for (int i = threadIdx.x; i < 2 * nst + ES_FAR_NODE(c, nchunks); i += blockDim.x)      // far node: first chunk only
+        sb[i * NB + f] = P.base[(size_t)f * P.npts + 2 * c0 + i];
     __syncthreads();
     if (c == nchunks - 1) {                            // last node: start vector of the march
 #pragma unroll
@@ -192,7 +201,7 @@ __device__ __forceinline__ void shoot_point_wavegroup_impl(const ShootDev& P, do
   for (int c = nchunks - 1; c >= 0; --c) {
     const int c0 = c * CHR;
     const int nst = (nsteps - c0 < CHR) ? (nsteps - c0) : CHR;
-    const int nn = 2 * nst + 1;
+    const int nn = 2 * nst + ES_FAR_NODE(c, nchunks);          // the far node's entries: only the chunk that starts the march reads them
     __builtin_amdgcn_wave_barrier();                   // previous chunk consumed by every lane of this wave
     for (int idx = lane; idx < NG * nn; idx += 64) {
       const int g2 = idx / nn, i = idx - g2 * nn;
