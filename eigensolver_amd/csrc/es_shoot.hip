@@ -1027,12 +1027,12 @@ constexpr bool shape_built() {
 #endif
 }
 
-// rows of at most 512 frequencies of the untwisted cylinder go two to a four-wave workgroup (shoot_grid_kernel_r2: 128 lanes x
-// ceil(nw / 128) points per row) unless the problem needs per-node sign tracking; ES_GRID_ROWS2=0 and ES_GRID_SHAPE select
+// rows of at most 512 frequencies of the band families (untwisted cylinder, slabs) go two to a four-wave workgroup
+// (shoot_grid_kernel_r2: 128 lanes x ceil(nw / 128) points per row) unless the problem needs per-node sign tracking; ES_GRID_ROWS2=0 and ES_GRID_SHAPE select
 // the one-row shapes (A/B aids)
 template <int FAM>
 bool rows2_shape(int nw, bool track) {
-  if (FAM != FAM_CYL0 || track || nw > 512) return false;
+  if (!fam_has_bands<FAM>() || track || nw > 512) return false;
   const char* r2 = getenv("ES_GRID_ROWS2");
   return !(r2 && r2[0] == '0') && !getenv("ES_GRID_SHAPE");
 }
@@ -1075,7 +1075,7 @@ int launch_grid(es_context* ctx, const es_problem* prob, const double* d_k, int 
   const dim3 grid = es_tile_grid(tiles);
   bool launched = false;
   es_timer_begin(ctx);
-  if constexpr (FAM == FAM_CYL0) {
+  if constexpr (fam_has_bands<FAM>()) {
     if (rows2_shape<FAM>(nw, track) && !opts.cols && nk >= 2) {
       const int pts2 = (nw + 127) / 128;
       const dim3 grid2 = es_tile_grid(((long)nk + 1) / 2);
@@ -1453,7 +1453,7 @@ extern "C" int es_shoot_grid_shape(es_context* ctx, const es_problem* prob, int 
     default: return ES_ERR_UNSUPPORTED;
   }
   *h_pts = g.pts; *h_wpe = g.wpe; *h_track = track ? 1 : 0;
-  if (prob->dev.family == FAM_CYL0 && rows2_shape<FAM_CYL0>(nw, track)) { *h_pts = -((nw + 127) / 128); *h_wpe = 3; }
+  if (prob->dev.family != FAM_CYLT && rows2_shape<FAM_CYL0>(nw, track)) { *h_pts = -((nw + 127) / 128); *h_wpe = 3; }
   return ES_SUCCESS;
 }
 

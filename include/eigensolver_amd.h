@@ -178,7 +178,7 @@ int es_shoot_eval_grid_ex(es_context* ctx, const es_problem* prob, const double*
  * lane, waves per SIMD of the register cap, per-node sign tracking on / off -- i.e. the instantiation
  * shoot_grid_kernel<family, pts, 256, track, wpe> that bench.py prices against profiles/isa_loop_counts.json.  A NEGATIVE
  * *h_pts = -p names the shape with two k-rows per workgroup, shoot_grid_kernel_r2<family, p, track, wpe> (rows of at most
- * 512 frequencies of the untwisted cylinder, at least two rows). */
+ * 512 frequencies of the untwisted cylinder and the slabs, at least two rows). */
 int es_shoot_grid_shape(es_context* ctx, const es_problem* prob, int nw, int* h_pts, int* h_wpe, int* h_track);
 
 /* The same determinant at n arbitrary (k, omega) pairs (one pair per lane, no shared k). */

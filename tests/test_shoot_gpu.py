@@ -629,13 +629,16 @@ def test_more_tiles_than_one_grid_dimension_holds(es_ctx):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("nk,nw", [(7, 384), (2, 100), (5, 512), (64, 129), (3, 257)])
-def test_two_rows_per_workgroup_bit_identical(es_ctx, monkeypatch, nk, nw):
-    """Rows of at most 512 frequencies of the untwisted cylinder are marched two to a workgroup (shoot_grid_kernel_r2); same
-    bits as the one-row shapes (ES_GRID_ROWS2=0), odd row counts and ragged widths included, per-row frequencies too."""
+@pytest.mark.parametrize("name,nk,nw", [("CF_flow_kink", 7, 384), ("CF_flow_kink", 2, 100), ("CF_flow_kink", 5, 512),
+                                        ("CF_flow_kink", 64, 129), ("CF_flow_kink", 3, 257), ("SD_w15_kink", 5, 300),
+                                        ("SFG_flow_kink", 9, 384), ("SFG_flow_kink", 4, 64)])
+def test_two_rows_per_workgroup_bit_identical(es_ctx, monkeypatch, name, nk, nw):
+    """Rows of at most 512 frequencies of the untwisted cylinder and the slabs are marched two to a workgroup
+    (shoot_grid_kernel_r2); same bits as the one-row shapes (ES_GRID_ROWS2=0), odd row counts and ragged widths included,
+    per-row frequencies too."""
     import ctypes as C
     from eigensolver_amd import _lib
-    case = CASES["CF_flow_kink"]
+    case = CASES[name]
     gp = _gpu_problem(es_ctx, case)
     k, W = cases.sample_kw(case, nk=nk, nw=nw, seed=11)
     pts, wpe, trk = C.c_int(0), C.c_int(0), C.c_int(0)
